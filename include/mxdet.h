@@ -1,0 +1,289 @@
+/*
+ * mxdet.h -- C-ABI of libmxdet_hip.so: the MI355X (gfx950) two-stage-detector hot path.
+ *
+ * Drop-in boundary. The reference (jiangzhengkai/mxdetection) declares the
+ * plugin slots only by name -- /root/reference/README.md:24 (`mxdetection/ops`), README.md:15-19
+ * (`core/{anchor,bbox,mask,loss}`), README.md:27-32 (`models/{backbones,rpn_heads,bbox_heads,
+ * mask_heads,necks,roi_extractors}`) -- and delegates all arithmetic to MXNet 1.3.0 operators
+ * (README.md:37). Each entry below names the slot it sits behind and the MXNet-1.3.0 operator whose
+ * role it takes; INTEGRATION.md shows the `mx.operator.CustomOp` / ctypes stub a maintainer would add.
+ *
+ * Conventions (every entry):
+ *   - raw device pointers + explicit sizes; no torch / MXNet types; the caller owns every buffer,
+ *     workspace included; the library never allocates device memory, frees, or keeps a pointer.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); re-entrant; no global mutable state
+ *     except the thread-local error string.
+ *   - returns 0 on success or a negative MXDET_E* code; never throws, aborts or prints.
+ *   - boxes are fp32 (x1,y1,x2,y2) in the legacy "+1" pixel convention; rois are (batch,x1,y1,x2,y2).
+ *   - activations are bf16 channels-last [N,H,W,C]; `bf16` buffers are passed as uint16_t*.
+ *   - `accumulate` on backward entries mirrors MXNet's req: 0 = kWriteTo, 1 = kAddTo.
+ */
+#ifndef MXDET_H_
+#define MXDET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXDET_OK 0
+#define MXDET_EINVAL (-1)
+#define MXDET_ESHAPE (-2)
+#define MXDET_EWORKSPACE (-3)
+#define MXDET_EHIP (-4)
+
+#define MXDET_DTYPE_F32 0
+#define MXDET_DTYPE_BF16 1
+
+typedef void* mxdet_stream_t; /* hipStream_t */
+
+/* thread-local description of the last failure on this thread ("" if none) */
+const char* mxdet_last_error(void);
+/* library version / build arch string, e.g. "mxdet-hip 0.1 gfx950" */
+const char* mxdet_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * core/bbox  (README.md:17)  -- bbox_overlaps; MXNet role: Cython bbox_overlaps / contrib.box_iou
+ * out[na,nb] = IoU(a_i, b_j), legacy +1 convention. */
+int mxdet_box_iou(const float* boxes_a, int64_t na, const float* boxes_b, int64_t nb, float* out,
+                  mxdet_stream_t stream);
+
+/* core/anchor (README.md:16) -- dense anchor grid of one pyramid level.
+ * out[(y*W+x)*A+a] = base[a] + (x*stride, y*stride, x*stride, y*stride). */
+int mxdet_generate_anchors(const float* base_anchors, int32_t A, int32_t H, int32_t W, int32_t stride,
+                           float* out, mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ops (README.md:24) -- batched NMS over B independent score-sorted lists.
+ * boxes[B,n_max,4] sorted by descending score; counts[B] valid entries per list; invalid[B,n_max]
+ * (may be NULL) marks boxes to drop before NMS. A box suppresses a later one when IoU > thresh.
+ * keep_idx[B,n_max] receives the kept positions in ascending order, num_keep[B] their number
+ * (at most max_keep each). MXNet role: contrib.box_nms / Cython cpu_nms / gpu_nms. */
+size_t mxdet_nms_batched_workspace_bytes(int32_t B, int32_t n_max);
+int mxdet_nms_batched(const float* boxes, const int32_t* counts, const uint8_t* invalid, int32_t B,
+                      int32_t n_max, float thresh, int32_t max_keep, int32_t* keep_idx,
+                      int32_t* num_keep, void* workspace, size_t workspace_bytes,
+                      mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * rpn_heads + ops (README.md:28, :24) -- pyramid proposal generation.
+ * MXNet role: contrib.Proposal / MultiProposal, or the lineage's pyramid-proposal CustomOp.
+ * Per image and level: top `pre_nms_top_n` anchors by objectness logit (ties: lower anchor index
+ * first) -> decode deltas at the anchors, clip to the image -> drop boxes with w or h < min_size ->
+ * NMS(thresh) -> at most post_nms_top_n per level; levels merged per image by (score desc, global
+ * anchor index asc) and cut to post_nms_top_n.
+ *
+ * Level l has H[l] x W[l] cells, A anchors per cell, feature stride stride[l]; its logits and deltas
+ * live in one tensor each, addressed with element strides so NCHW and NHWC producers both fit:
+ *   score(n,y,x,a)   = cls[l][n*cls_sn[l] + y*cls_sy[l] + x*cls_sx[l] + a*cls_sa[l]]
+ *   delta(n,y,x,a,k) = reg[l][n*reg_sn[l] + y*reg_sy[l] + x*reg_sx[l] + (a*4+k)*reg_sc[l]]
+ * Outputs: rois[N,post_nms_top_n,5] (batch index, box; zero padded), roi_scores[N,post_nms_top_n],
+ * roi_anchor[N,post_nms_top_n] (global anchor index, -1 padding), num_rois[N]. */
+typedef struct {
+  int32_t num_levels;       /* <= 8 */
+  int32_t A;                /* anchors per cell */
+  int32_t H[8], W[8], stride[8];
+  const void* cls[8];
+  const void* reg[8];
+  int64_t cls_sn[8], cls_sy[8], cls_sx[8], cls_sa[8];
+  int64_t reg_sn[8], reg_sy[8], reg_sx[8], reg_sc[8];
+  int32_t dtype;            /* MXDET_DTYPE_F32 | MXDET_DTYPE_BF16 (both tensors) */
+  const float* base_anchors[8]; /* device, [A,4] per level */
+} mxdet_pyramid_t;
+
+size_t mxdet_proposal_workspace_bytes(const mxdet_pyramid_t* p, int32_t N, int32_t pre_nms_top_n);
+int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* im_info /* [N,3] h,w,scale */,
+                   int32_t pre_nms_top_n, int32_t post_nms_top_n, float nms_thresh, float min_size,
+                   float* rois, float* roi_scores, int32_t* roi_anchor, int32_t* num_rois,
+                   void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * core/anchor (README.md:16) -- anchor <-> GT assignment and RPN target sampling.
+ * anchors[A_total,4]; gt_boxes[N,G_max,5] (x1,y1,x2,y2,class; rows with class < 0 are padding).
+ * label = 1 if max IoU >= fg_thresh or the anchor attains some GT's maximum IoU (> 0);
+ *         0 if max IoU < bg_thresh; -1 otherwise; anchors reaching outside the image by more than
+ * allowed_border are -1. Then subsample to `batch_size` per image (at most fg_fraction*batch_size
+ * foreground) with Philox keys (mxdet_math.h: mxdet_sample_key, streams 0/1); batch_size <= 0 keeps
+ * every label (RetinaNet). Outputs: labels[N,A_total] int32, matched_gt[N,A_total] int32 (argmax GT,
+ * lowest index on ties), bbox_targets[N,A_total,4] (encoded for label==1, else 0),
+ * max_iou[N,A_total] (may be NULL). */
+size_t mxdet_anchor_target_workspace_bytes(int32_t N, int64_t A_total, int32_t G_max);
+int mxdet_anchor_target(const float* anchors, int64_t A_total, const float* gt_boxes, int32_t N,
+                        int32_t G_max, const float* im_info, float fg_thresh, float bg_thresh,
+                        float allowed_border, int32_t batch_size, float fg_fraction, uint32_t seed,
+                        uint32_t step, uint32_t image_offset, int32_t* labels, int32_t* matched_gt,
+                        float* bbox_targets, float* max_iou, void* workspace, size_t workspace_bytes,
+                        mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * core/bbox (README.md:17) -- proposal-target: RoI sampling for the box head.
+ * Candidates of image n = its first num_rois[n] proposals followed by its valid GT boxes.
+ * fg: max IoU >= fg_thresh; bg: bg_lo <= max IoU < bg_hi. Sample min(fg_fraction*rois_per_image,
+ * #fg) foreground and fill up with background, both by Philox keys (streams 2/3); selected rois are
+ * written foreground first, each group in ascending candidate order; unfilled slots are padding
+ * (label -1, zero box, zero weights).
+ * Outputs: out_rois[N,R,5], labels[N,R] int32 (class, 0 = background), bbox_targets[N,R,4*num_reg]
+ * and bbox_weights[N,R,4*num_reg] (class-specific slot, normalised (t-mean)/std), matched_gt[N,R],
+ * num_fg[N]. num_reg = num_classes (class-specific) or 1 (class-agnostic). */
+int mxdet_proposal_target(const float* rois, const int32_t* num_rois, int32_t rois_stride,
+                          const float* gt_boxes, int32_t N, int32_t G_max, int32_t rois_per_image,
+                          float fg_fraction, float fg_thresh, float bg_hi, float bg_lo,
+                          int32_t num_classes, int32_t class_agnostic,
+                          const float* means /* HOST [4] */, const float* stds /* HOST [4] */,
+                          uint32_t seed, uint32_t step,
+                          uint32_t image_offset, float* out_rois, int32_t* labels,
+                          float* bbox_targets, float* bbox_weights, int32_t* matched_gt,
+                          int32_t* num_fg, mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * roi_extractors (README.md:32) -- FPN level map + RoIAlign. MXNet role: contrib.ROIAlign
+ * (Detectron aligned=False semantics), one call covering all pyramid levels.
+ * feats[l]: bf16 [N,H[l],W[l],C] channels-last; rois[R,5]; levels[R] int32 in [lvl_min, lvl_min+L).
+ * out: bf16 [R,PH,PW,C]. Bilinear taps in fp32 in the fixed order ((w1*v1+w2*v2)+w3*v3)+w4*v4,
+ * samples summed iy-major then ix, times 1/count, rounded to bf16 once. */
+int mxdet_fpn_level_map(const float* rois, int64_t R, int32_t lvl_min, int32_t lvl_max,
+                        int32_t* levels, mxdet_stream_t stream);
+typedef struct {
+  int32_t num_levels, lvl_min;
+  int32_t H[8], W[8];
+  float spatial_scale[8];
+  void* feat[8]; /* bf16 [N,H,W,C]; for bwd: fp32 gradient accumulators of the same shape */
+} mxdet_feat_pyramid_t;
+int mxdet_roi_align_fwd(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
+                        const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
+                        int32_t sampling_ratio, uint16_t* out, mxdet_stream_t stream);
+/* bwd: scatter-adds grad_out (bf16 [R,PH,PW,C]) into fp32 [N,H,W,C] accumulators f->feat[l]
+ * (caller zeroes them for accumulate = 0 semantics). fp32 atomics: order-dependent in the last bits. */
+int mxdet_roi_align_bwd(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
+                        const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
+                        int32_t sampling_ratio, const uint16_t* grad_out, mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * core/loss (README.md:19)
+ * smooth-L1 (MXNet smooth_l1(scalar=sigma)): elementwise on (pred - target) * weight. */
+int mxdet_smooth_l1_fwd(const float* pred, const float* target, const float* weight, int64_t n,
+                        float sigma, float* out, mxdet_stream_t stream);
+int mxdet_smooth_l1_bwd(const float* pred, const float* target, const float* weight,
+                        const float* grad_out, int64_t n, float sigma, int32_t accumulate,
+                        float* grad_pred, mxdet_stream_t stream);
+
+/* Sigmoid focal loss (RetinaNet): logits [n,C] (dtype f32|bf16), labels[n] int32 (-1 ignore,
+ * 0 background, c in 1..C foreground class c), normaliser = max(1, #foreground) computed on device.
+ * loss_out[1] fp32 (sum / normaliser, fixed reduction order); grad written in the logits dtype.
+ * workspace: mxdet_loss_workspace_bytes(n). */
+size_t mxdet_loss_workspace_bytes(int64_t n);
+int mxdet_focal_loss(const void* logits, int32_t dtype, const int32_t* labels, int64_t n, int32_t C,
+                     float alpha, float gamma, float grad_scale, float* loss_out, void* grad_logits,
+                     void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+
+/* RPN losses fused fwd+bwd over one pyramid level's head output.
+ * head: bf16 [N,H,W,Cpad] channels-last, channel a = objectness logit of anchor a, channel
+ * A + 4a + k = delta k of anchor a. labels / bbox_targets are the mxdet_anchor_target outputs
+ * (global anchor order), level_offset = index of this level's first anchor.
+ * cls: sigmoid BCE over label >= 0; reg: smooth-L1(sigma) over label == 1; both * norm
+ * (norm = 1 / sampled batch, chosen by the caller). Partial sums are appended to
+ * partial[2*num_blocks] and reduced in fixed order by mxdet_loss_finalize.
+ * grad_head: bf16 [N,H,W,Cpad] = d(loss)/d(head) * loss_scale (channels >= 5A are written 0).
+ * Per-workgroup partial sums (cls, reg) go to partial[2*i + {0,1}], i < mxdet_rpn_loss_num_partials;
+ * the caller lays the levels' partial ranges back to back and reduces them in index order with
+ * mxdet_loss_finalize, so the scalar losses are reproducible bit for bit. */
+int32_t mxdet_rpn_loss_num_partials(int32_t N, int32_t H, int32_t W);
+int mxdet_rpn_loss_level(const uint16_t* head, int32_t N, int32_t H, int32_t W, int32_t A,
+                         int32_t Cpad, const int32_t* labels, const float* bbox_targets,
+                         int64_t A_total, int64_t level_offset, float sigma, float norm,
+                         float loss_scale, uint16_t* grad_head, float* partial,
+                         mxdet_stream_t stream);
+/* out[j] = sum over i < count of partial[i*ncomp + j], fixed order, one workgroup */
+int mxdet_loss_finalize(const float* partial, int32_t count, int32_t ncomp, float* out,
+                        mxdet_stream_t stream);
+
+/* Box-head losses fused fwd+bwd. cls_logits: [R,num_classes] (dtype), softmax CE with ignore label
+ * -1, normalised by norm; bbox_pred [R,4*num_reg] vs targets/weights, smooth-L1(sigma) * norm.
+ * loss_out[2] = (cls, reg); grads written in the logits dtype scaled by loss_scale. */
+int mxdet_rcnn_loss(const void* cls_logits, const void* bbox_pred, int32_t dtype, int32_t ld_cls,
+                    int32_t ld_reg, const int32_t* labels, const float* bbox_targets,
+                    const float* bbox_weights, int64_t R, int32_t num_classes, int32_t reg_dim,
+                    float sigma, float norm, float loss_scale, float* loss_out, void* grad_cls,
+                    void* grad_reg, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * backbones / necks / rpn_heads / bbox_heads / mask_heads (README.md:27-31) -- dense contractions.
+ * MXNet roles: Convolution (+ BatchNorm(use_global_stats) + Activation + elemwise_add),
+ * FullyConnected, Pooling, UpSampling. All bf16 in / fp32 accumulate on MFMA / bf16 out.
+ *
+ * conv2d: x bf16 [N,H,W,Cin] channels-last, w bf16 [Cout,KH,KW,Cin], y bf16 [N,Ho,Wo,Cout].
+ * Epilogue: y = act( conv + bias[c] + residual ), residual optional, of shape y or -- with
+ * res_upsample = 1 -- [N,ceil(Ho/2),ceil(Wo/2),Cout] read nearest-neighbour (FPN top-down add).
+ * A fully-connected layer is the 1x1 case with H = W = 1 and N = rows. */
+typedef struct {
+  int32_t N, H, W, Cin;      /* input  */
+  int32_t Cout, KH, KW;      /* filter */
+  int32_t stride, pad;       /* same in both dims */
+  int32_t Ho, Wo;            /* output; must equal floor((H + 2*pad - KH)/stride) + 1 etc. */
+  int32_t relu;              /* fwd: apply ReLU;   dgrad: multiply by (mask > 0) */
+  int32_t res_upsample;      /* fwd only */
+  int32_t accumulate;        /* dgrad / wgrad: add into the output instead of overwriting */
+} mxdet_conv_desc_t;
+
+int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w,
+                     const float* bias, const uint16_t* residual, uint16_t* y,
+                     mxdet_stream_t stream);
+/* dgrad: dx[N,H,W,Cin] = sum over taps dy[N,Ho,Wo,Cout] * w, with wt = the same filter stored
+ * [Cin,KH,KW,Cout] (mxdet_filter_transpose). If d->relu, dx is multiplied by (relu_mask > 0) where
+ * relu_mask is the forward activation x (bf16, post-ReLU). If d->accumulate, dx += (bf16). */
+int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy, const uint16_t* wt,
+                       const uint16_t* relu_mask, uint16_t* dx, mxdet_stream_t stream);
+/* wgrad: dw fp32 [Cout,KH,KW,Cin] (+)= sum over pixels dy * x; deterministic split-K through
+ * workspace slabs reduced in fixed order; db fp32 [Cout] (may be NULL) (+)= sum over pixels dy. */
+size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d);
+int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* dy, float* dw,
+                       float* db, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+/* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
+int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
+                           uint16_t* wt, mxdet_stream_t stream);
+
+/* stem: 7x7 stride-2 pad-3 convolution reading the NCHW fp32/bf16 image [N,3,H,W] directly
+ * (coalesced plane reads), + bias + ReLU, writing bf16 [N,Ho,Wo,64]; w bf16 [64,7,7,3]. */
+int mxdet_stem_conv7x7(const void* image, int32_t dtype, int32_t N, int32_t H, int32_t W,
+                       const uint16_t* w, const float* bias, uint16_t* y, mxdet_stream_t stream);
+/* 3x3 stride-2 pad-1 max pooling, bf16 channels-last */
+int mxdet_maxpool3x3s2(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y,
+                       mxdet_stream_t stream);
+/* y[N,ceil(H/2),ceil(W/2),C] = x[N, 2i, 2j, C]  (FPN P6) and its adjoint (scatter into zeros / add) */
+int mxdet_subsample2(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y,
+                     mxdet_stream_t stream);
+/* adjoint of the nearest-neighbour 2x upsample: dcoarse[N,Hc,Wc,C] (+)= sum of the 2x2 fine cells */
+int mxdet_upsample2_bwd(const uint16_t* dfine, int32_t N, int32_t Hf, int32_t Wf, int32_t C,
+                        int32_t accumulate, uint16_t* dcoarse, mxdet_stream_t stream);
+/* elementwise helpers on channels-last tensors */
+int mxdet_add_bf16(const uint16_t* a, const uint16_t* b, int64_t n, uint16_t* out,
+                   mxdet_stream_t stream);
+int mxdet_relu_bwd_bf16(const uint16_t* dy, const uint16_t* y, int64_t n, uint16_t* dx,
+                        mxdet_stream_t stream);
+int mxdet_f32_to_bf16(const float* x, int64_t n, uint16_t* y, mxdet_stream_t stream);
+/* y[i] (+)= bf16(x[i]) as fp32->bf16 with optional mask y*(mask>0): used to fold the RoIAlign
+ * fp32 gradient accumulators into the bf16 pyramid gradients */
+int mxdet_f32_accum_to_bf16(const float* x, int64_t n, int32_t accumulate, uint16_t* y,
+                            mxdet_stream_t stream);
+/* layout converters at the boundary (MXNet tensors are NCHW) */
+int mxdet_nchw_to_nhwc_bf16(const void* x, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                            uint16_t* y, mxdet_stream_t stream);
+int mxdet_nhwc_to_nchw_f32(const uint16_t* x, int32_t N, int32_t C, int32_t H, int32_t W, float* y,
+                           mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * optimizer step (MXNet role: sgd_mom_update after kvstore reduce).
+ * Flat fp32 parameter / gradient / momentum arenas of n elements:
+ *   g = grad * rescale (+ wd * w);  m = momentum * m + g;  w -= lr_mult[i] * lr * m
+ * and the bf16 working copy of w is refreshed in the same pass. per-element scale arrays may be
+ * NULL. */
+int mxdet_sgd_momentum_update(float* w, const float* grad, float* mom, uint16_t* w_bf16, int64_t n,
+                              float lr, float momentum, float wd, float rescale,
+                              mxdet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXDET_H_ */

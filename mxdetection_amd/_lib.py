@@ -1,0 +1,139 @@
+"""ctypes binding of libmxdet_hip.so (the C-ABI in include/mxdet.h).
+
+The product path has no CPU fallback: if the HIP library is missing, importing an op raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmxdet_hip.so")
+
+c_i32, c_i64, c_u32, c_f32, c_sz, c_vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_size_t, C.c_void_p
+
+
+class PyramidT(C.Structure):
+    _fields_ = [
+        ("num_levels", c_i32), ("A", c_i32),
+        ("H", c_i32 * 8), ("W", c_i32 * 8), ("stride", c_i32 * 8),
+        ("cls", c_vp * 8), ("reg", c_vp * 8),
+        ("cls_sn", c_i64 * 8), ("cls_sy", c_i64 * 8), ("cls_sx", c_i64 * 8), ("cls_sa", c_i64 * 8),
+        ("reg_sn", c_i64 * 8), ("reg_sy", c_i64 * 8), ("reg_sx", c_i64 * 8), ("reg_sc", c_i64 * 8),
+        ("dtype", c_i32),
+        ("base_anchors", c_vp * 8),
+    ]
+
+
+class FeatPyramidT(C.Structure):
+    _fields_ = [
+        ("num_levels", c_i32), ("lvl_min", c_i32),
+        ("H", c_i32 * 8), ("W", c_i32 * 8),
+        ("spatial_scale", c_f32 * 8),
+        ("feat", c_vp * 8),
+    ]
+
+
+class ConvDescT(C.Structure):
+    _fields_ = [
+        ("N", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32),
+        ("Cout", c_i32), ("KH", c_i32), ("KW", c_i32),
+        ("stride", c_i32), ("pad", c_i32),
+        ("Ho", c_i32), ("Wo", c_i32),
+        ("relu", c_i32), ("res_upsample", c_i32), ("accumulate", c_i32),
+    ]
+
+
+P = C.POINTER
+
+# name -> (restype, argtypes). Every symbol include/mxdet.h declares must appear here
+# (tests/test_abi.py checks the header against this table and the built library).
+SIGNATURES = {
+    "mxdet_last_error": (C.c_char_p, []),
+    "mxdet_version": (C.c_char_p, []),
+    "mxdet_box_iou": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "mxdet_generate_anchors": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_nms_batched_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "mxdet_nms_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_proposal_workspace_bytes": (c_sz, [P(PyramidT), c_i32, c_i32]),
+    "mxdet_proposal": (c_i32, [P(PyramidT), c_i32, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
+                               c_vp, c_sz, c_vp]),
+    "mxdet_anchor_target_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32]),
+    "mxdet_anchor_target": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_f32, c_f32, c_f32, c_i32, c_f32,
+                                    c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_proposal_target": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32,
+                                      c_i32, c_i32, P(c_f32), P(c_f32), c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, c_vp, c_vp]),
+    "mxdet_fpn_level_map": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_roi_align_fwd": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp,
+                                    c_vp]),
+    "mxdet_roi_align_bwd": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp,
+                                    c_vp]),
+    "mxdet_smooth_l1_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
+    "mxdet_smooth_l1_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_i32, c_vp, c_vp]),
+    "mxdet_loss_workspace_bytes": (c_sz, [c_i64]),
+    "mxdet_focal_loss": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz,
+                                 c_vp]),
+    "mxdet_rpn_loss_num_partials": (c_i32, [c_i32, c_i32, c_i32]),
+    "mxdet_rpn_loss_level": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32,
+                                     c_f32, c_f32, c_vp, c_vp, c_vp]),
+    "mxdet_loss_finalize": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_rcnn_loss": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32,
+                                c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_conv2d_fwd": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mxdet_conv2d_wgrad_workspace_bytes": (c_sz, [P(ConvDescT)]),
+    "mxdet_conv2d_wgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_stem_conv7x7": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mxdet_maxpool3x3s2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_subsample2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_upsample2_bwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_add_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "mxdet_relu_bwd_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "mxdet_f32_to_bf16": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    "mxdet_f32_accum_to_bf16": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "mxdet_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_sgd_momentum_update": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
+}
+
+_lib = None
+
+
+class MxdetError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmxdet_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MxdetError(
+            "libmxdet_hip.so not found at %s -- build it with `python -m mxdetection_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)  # tests/test_abi.py asserts that no declared symbol is missing
+        if fn is None:
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mxdet_last_error().decode("utf-8", "replace")
+        raise MxdetError("%s failed (%d): %s" % (what or "mxdet call", rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,90 @@
+// common.h -- shared host/device helpers for libmxdet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mxdet.h"
+#include "../../include/mxdet_math.h"
+
+namespace mxdet {
+
+// thread-local error string (the only mutable global state of the library)
+void set_error(const char* fmt, ...);
+void clear_error();
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return MXDET_EHIP;
+  }
+  return MXDET_OK;
+}
+
+#define MXDET_REQUIRE(cond, code, ...)  \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::mxdet::set_error(__VA_ARGS__);  \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+static inline hipStream_t as_stream(mxdet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;
+
+template <typename T>
+__host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return mxdet_f32_to_bf16(f); }
+
+__device__ __forceinline__ float load_as_f32(const void* p, int64_t i, int dtype) {
+  if (dtype == MXDET_DTYPE_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+  return ((const float*)p)[i];
+}
+__device__ __forceinline__ void store_from_f32(void* p, int64_t i, int dtype, float v) {
+  if (dtype == MXDET_DTYPE_BF16)
+    ((uint16_t*)p)[i] = f32_to_bf16_bits(v);
+  else
+    ((float*)p)[i] = v;
+}
+
+// wave-level inclusive/exclusive helpers (wave = 64)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int wave_excl_count(bool pred, int* total) {
+  unsigned long long m = __ballot(pred);
+  int lane = lane_id();
+  unsigned long long below = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
+  *total = __popcll(m);
+  return __popcll(below);
+}
+
+// Block-wide exclusive prefix count of a predicate in thread order; returns this thread's rank and
+// the block total. `scratch` must hold (blockDim.x/64 + 1) ints. Contains __syncthreads.
+__device__ inline int block_excl_count(bool pred, int* scratch, int* total) {
+  int wtot;
+  int r = wave_excl_count(pred, &wtot);
+  int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();  // protect scratch reuse
+  if (lane_id() == 0) scratch[wid] = wtot;
+  __syncthreads();
+  int base = 0, all = 0;
+  for (int i = 0; i < nw; ++i) {
+    int v = scratch[i];
+    if (i < wid) base += v;
+    all += v;
+  }
+  *total = all;
+  return base + r;
+}
+
+}  // namespace mxdet

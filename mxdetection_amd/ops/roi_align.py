@@ -1,0 +1,48 @@
+"""ops: FPN level map + multi-level RoIAlign (MXNet role: contrib.ROIAlign)."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import FeatPyramidT, check, ptr, stream_ptr
+
+
+def fpn_level_map(rois, lvl_min=2, lvl_max=5):
+    lib = _lib.load()
+    R = rois.shape[0]
+    levels = torch.empty((R,), dtype=torch.int32, device=rois.device)
+    check(lib.mxdet_fpn_level_map(ptr(rois), R, lvl_min, lvl_max, ptr(levels), stream_ptr()), "fpn_level_map")
+    return levels
+
+
+def _pyr(feats, scales, lvl_min):
+    d = FeatPyramidT()
+    d.num_levels, d.lvl_min = len(feats), lvl_min
+    for l, f in enumerate(feats):
+        d.H[l], d.W[l] = f.shape[1], f.shape[2]
+        d.spatial_scale[l] = scales[l]
+        d.feat[l] = f.data_ptr()
+    return d
+
+
+def roi_align_forward(feats, scales, rois, levels, pooled=(7, 7), sampling_ratio=2, lvl_min=2, out=None):
+    """feats[l]: bf16 [N,H,W,C]; rois [R,5] f32; levels [R] i32 -> bf16 [R,PH,PW,C]."""
+    lib = _lib.load()
+    N, C_ = feats[0].shape[0], feats[0].shape[3]
+    R = rois.shape[0]
+    if out is None:
+        out = torch.empty((R, pooled[0], pooled[1], C_), dtype=torch.bfloat16, device=rois.device)
+    d = _pyr(feats, scales, lvl_min)
+    check(lib.mxdet_roi_align_fwd(C.byref(d), N, C_, ptr(rois), ptr(levels), R, pooled[0], pooled[1], sampling_ratio,
+                                  ptr(out), stream_ptr()), "roi_align_fwd")
+    return out
+
+
+def roi_align_backward(dfeats, scales, rois, levels, grad_out, sampling_ratio=2, lvl_min=2):
+    """Scatter-adds grad_out (bf16 [R,PH,PW,C]) into the fp32 accumulators dfeats[l] ([N,H,W,C])."""
+    lib = _lib.load()
+    N, C_ = dfeats[0].shape[0], dfeats[0].shape[3]
+    R, PH, PW = grad_out.shape[0], grad_out.shape[1], grad_out.shape[2]
+    d = _pyr(dfeats, scales, lvl_min)
+    check(lib.mxdet_roi_align_bwd(C.byref(d), N, C_, ptr(rois), ptr(levels), R, PH, PW, sampling_ratio,
+                                  ptr(grad_out), stream_ptr()), "roi_align_bwd")
