@@ -230,11 +230,14 @@ typedef struct {
 int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w,
                      const float* bias, const uint16_t* residual, uint16_t* y,
                      mxdet_stream_t stream);
-/* dgrad: dx[N,H,W,Cin] = sum over taps dy[N,Ho,Wo,Cout] * w, with wt = the same filter stored
- * [Cin,KH,KW,Cout] (mxdet_filter_transpose). If d->relu, dx is multiplied by (relu_mask > 0) where
- * relu_mask is the forward activation x (bf16, post-ReLU). If d->accumulate, dx += (bf16). */
+/* dgrad: dx[N,H,W,Cin] = (sum over taps dy[N,Ho,Wo,Cout] * w  +  residual) * (relu_mask > 0), with
+ * wt = the same filter stored [Cin,KH,KW,Cout] (mxdet_filter_transpose). residual (bf16, shape of dx;
+ * may be NULL) is the gradient arriving over a parallel branch (identity shortcut / sibling conv);
+ * d->accumulate with residual == NULL means residual = dx. The mask factor applies only if d->relu:
+ * relu_mask is then the forward activation x (bf16, post-ReLU). */
 int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy, const uint16_t* wt,
-                       const uint16_t* relu_mask, uint16_t* dx, mxdet_stream_t stream);
+                       const uint16_t* residual, const uint16_t* relu_mask, uint16_t* dx,
+                       mxdet_stream_t stream);
 /* wgrad: dw fp32 [Cout,KH,KW,Cin] (+)= sum over pixels dy * x; deterministic split-K through
  * workspace slabs reduced in fixed order; db fp32 [Cout] (may be NULL) (+)= sum over pixels dy. */
 size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d);
@@ -254,6 +257,8 @@ int mxdet_maxpool3x3s2(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32
 /* y[N,ceil(H/2),ceil(W/2),C] = x[N, 2i, 2j, C]  (FPN P6) and its adjoint (scatter into zeros / add) */
 int mxdet_subsample2(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y,
                      mxdet_stream_t stream);
+int mxdet_subsample2_bwd(const uint16_t* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t accumulate, uint16_t* dx, mxdet_stream_t stream);
 /* adjoint of the nearest-neighbour 2x upsample: dcoarse[N,Hc,Wc,C] (+)= sum of the 2x2 fine cells */
 int mxdet_upsample2_bwd(const uint16_t* dfine, int32_t N, int32_t Hf, int32_t Wf, int32_t C,
                         int32_t accumulate, uint16_t* dcoarse, mxdet_stream_t stream);

@@ -79,13 +79,14 @@ SIGNATURES = {
     "mxdet_rcnn_loss": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32,
                                 c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_conv2d_fwd": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_conv2d_wgrad_workspace_bytes": (c_sz, [P(ConvDescT)]),
     "mxdet_conv2d_wgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_stem_conv7x7": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_maxpool3x3s2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_subsample2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_subsample2_bwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_upsample2_bwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_add_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "mxdet_relu_bwd_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),

@@ -1,0 +1,338 @@
+// wgrad.hip -- bf16 weight-gradient convolution on MFMA for gfx950 (deterministic split-K).
+//
+// Slots: backbones / necks / rpn_heads / bbox_heads / mask_heads (/root/reference/README.md:27-31);
+// MXNet role: Convolution / FullyConnected backward-weights (README.md:37).
+//
+//   dW[co][kh][kw][ci] = sum over output pixels m of dY[m][co] * X[src(m,kh,kw)][ci]
+//
+// GEMM view per tap: rows = co, cols = ci, reduction = pixels. Both operands are channels-last, i.e.
+// the reduction index is the *strided* one, so the MFMA fragments (8 consecutive k per lane) are
+// columns of the LDS image: they are fetched with ds_read_b64_tr_b16 (the CDNA4 transposing LDS
+// read), two per fragment. LDS images are [pixel][128 ch] with the 32-B granule index XOR-swizzled
+// by (row&3)|((row>>3)&1)<<2, which makes every transposed read conflict-free.
+// The pixel range is split over `ksplit` workgroups per tile; each writes an fp32 slab and a second
+// kernel adds the slabs in index order (bit-reproducible, no float atomics) and optionally accumulates
+// into dw (filters shared across pyramid levels: RPN head).
+#include "common.h"
+
+namespace mxdet {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct WgradP {
+  const uint16_t* x;   // [N,H,W,Cin]
+  const uint16_t* dy;  // [N,Ho,Wo,Cout]
+  float* slab;         // [ksplit][Cout][KH*KW*Cin]
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int M;               // N*Ho*Wo
+  int co_tiles, ci_tiles, ksplit, steps_per_split;
+};
+
+// byte offset inside a [64 px][256 B] image of 16-B chunk c16 of pixel row `row`
+__device__ __forceinline__ int wg_off(int row, int c16) {
+  int f = (row & 3) | (((row >> 3) & 1) << 2);
+  return row * 256 + ((((c16 >> 1) ^ f) << 5) | ((c16 & 1) << 4));
+}
+
+__device__ __forceinline__ s16x4_t tr_read(const unsigned char* lds_base, int byte_off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(lds_base + byte_off));
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_kernel(WgradP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][64 * 256];  // [buf][dy|x]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  int b = blockIdx.x;
+  const int ks = b % p.ksplit; b /= p.ksplit;
+  const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
+  const int co_t = b % p.co_tiles; b /= p.co_tiles;
+  const int tap = b;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co0 = co_t * 128, ci0 = ci_t * 128;
+
+  const int c16 = tid & 15, r0 = tid >> 4;   // 16 threads per pixel row, 16 rows per pass, 4 passes
+  const bool co_ok = (co0 + c16 * 8) < p.Cout;
+  const bool ci_ok = (ci0 + c16 * 8) < p.Cin;
+  const int step0 = ks * p.steps_per_split;
+  int nsteps = ceil_div(p.M, 64) - step0;
+  nsteps = nsteps > p.steps_per_split ? p.steps_per_split : nsteps;
+
+  uint4 gy[4], gx[4];
+  auto load_tiles = [&](int step) {
+    int mbase = (step0 + step) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = mbase + r0 + 16 * i;
+      uint4 vy = make_uint4(0u, 0u, 0u, 0u), vx = make_uint4(0u, 0u, 0u, 0u);
+      if (m < p.M) {
+        if (co_ok) vy = *(const uint4*)(p.dy + (size_t)m * p.Cout + co0 + c16 * 8);
+        int img = m / (p.Ho * p.Wo);
+        int rem = m - img * (p.Ho * p.Wo);
+        int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+        if (ci_ok && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W)
+          vx = *(const uint4*)(p.x + ((size_t)(img * p.H + hi) * p.W + wi) * p.Cin + ci0 + c16 * 8);
+      }
+      gy[i] = vy;
+      gx[i] = vx;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = wg_off(r0 + 16 * i, c16);
+      *(uint4*)(smem[buf][0] + off) = gy[i];
+      *(uint4*)(smem[buf][1] + off) = gx[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read geometry: lane 16g + 4q + pp addresses row 8g+q (+4), channels 4pp..4pp+3 of the
+  // 16-channel block; it receives channel (lane&15) of those four pixel rows.
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+
+  if (nsteps > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) load_tiles(st + 1);
+    const unsigned char* sy = smem[cur][0];
+    const unsigned char* sx = smem[cur][1];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int rowa = kk * 32 + 8 * g + q;       // first 4 pixel rows of this lane group's k-range
+      const int rowb = rowa + 4;
+      const int fa = (rowa & 3) | (((rowa >> 3) & 1) << 2);
+      const int fb = (rowb & 3) | (((rowb >> 3) & 1) << 2);
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int cgi = wm * 4 + i;   // 16-channel granule of the co tile
+        s16x4_t lo = tr_read(sy, rowa * 256 + ((cgi ^ fa) << 5) + pp * 8);
+        s16x4_t hi = tr_read(sy, rowb * 256 + ((cgi ^ fb) << 5) + pp * 8);
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int cgj = wn * 4 + j;
+        s16x4_t lo = tr_read(sx, rowa * 256 + ((cgj ^ fa) << 5) + pp * 8);
+        s16x4_t hi = tr_read(sx, rowb * 256 + ((cgj ^ fb) << 5) + pp * 8);
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // slab[ks][co][tap][ci]; D layout: col = lane&15 -> ci, row = (lane>>4)*4 + r -> co
+  const size_t Ktot = (size_t)p.KH * p.KW * p.Cin;
+  float* slab = p.slab + (size_t)ks * p.Cout * Ktot;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int ci = ci0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int co = co0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Cout && ci < p.Cin) slab[(size_t)co * Ktot + (size_t)tap * p.Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[i] (+)= sum_ks slab[ks][i]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int ksplit, long long n,
+                                    int accumulate, float* __restrict__ dw) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 s = *(const float4*)(slab + i);
+  for (int k = 1; k < ksplit; ++k) {
+    float4 v = *(const float4*)(slab + (long long)k * n + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (accumulate) {
+    float4 o = *(const float4*)(dw + i);
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  *(float4*)(dw + i) = s;
+}
+
+// bias gradient: column sums of dy [M][C] in two fixed-order stages
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const uint16_t* __restrict__ dy, int M, int C, int rows_per_block,
+                      float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = (float*)smem_raw;   // [row lanes][C]
+  const int CG = C >> 3;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int RL = 256 / CG;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int m0 = blockIdx.x * rows_per_block;
+  int m1 = m0 + rows_per_block;
+  m1 = m1 > M ? M : m1;
+  if (rl < RL)
+    for (int m = m0 + rl; m < m1; m += RL) {
+      uint4 v = *(const uint4*)(dy + (size_t)m * C + cg * 8);
+      s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+      s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+      s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+      s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+    }
+  if (rl < RL)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl * C + cg * 8 + k] = s[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += red[r * C + c];
+    partial[(size_t)blockIdx.x * C + c] = t;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                    int accumulate, float* __restrict__ db) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) t += partial[(size_t)b * C + c];
+  db[c] = accumulate ? db[c] + t : t;
+}
+
+// w [Cout][taps][Cin] -> wt [Cin][taps][Cout]
+__global__ void filter_transpose_kernel(const uint16_t* __restrict__ w, int Cout, int taps, int Cin,
+                                        uint16_t* __restrict__ wt) {
+  __shared__ uint16_t tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int co = co0 + r, ci = ci0 + threadIdx.x;
+    uint16_t v = 0;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * taps + tap) * Cin + ci];
+    tile[r][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int ci = ci0 + r, co = co0 + threadIdx.x;
+    if (co < Cout && ci < Cin) wt[((size_t)ci * taps + tap) * Cout + co] = tile[threadIdx.x][r];
+  }
+}
+
+struct WgradPlan {
+  int co_tiles, ci_tiles, taps, ksplit, steps_per_split;
+  size_t slab_bytes, colsum_off, colsum_bytes, total;
+  int colsum_blocks, colsum_rows;
+};
+
+static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
+  WgradPlan w;
+  w.co_tiles = ceil_div(d->Cout, 128);
+  w.ci_tiles = ceil_div(d->Cin, 128);
+  w.taps = d->KH * d->KW;
+  long long M = (long long)d->N * d->Ho * d->Wo;
+  int steps = (int)ceil_div<long long>(M, 64);
+  int tiles = w.co_tiles * w.ci_tiles * w.taps;
+  // aim for ~4 workgroups per CU overall, at least 8 steps per split
+  int want = ceil_div(1024, tiles);
+  int maxsplit = steps / 8 > 0 ? steps / 8 : 1;
+  int ks = want < maxsplit ? want : maxsplit;
+  ks = ks < 1 ? 1 : (ks > 64 ? 64 : ks);
+  w.steps_per_split = ceil_div(steps, ks);
+  w.ksplit = ceil_div(steps, w.steps_per_split);
+  size_t params = (size_t)d->Cout * w.taps * d->Cin;
+  w.slab_bytes = align_up((size_t)w.ksplit * params * sizeof(float), 256);
+  w.colsum_rows = 2048;
+  w.colsum_blocks = (int)ceil_div<long long>(M, w.colsum_rows);
+  w.colsum_off = w.slab_bytes;
+  w.colsum_bytes = align_up((size_t)w.colsum_blocks * d->Cout * sizeof(float), 256);
+  w.total = w.slab_bytes + w.colsum_bytes;
+  return w;
+}
+
+}  // namespace mxdet
+
+using namespace mxdet;
+
+extern "C" size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d) {
+  if (!d || d->N <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->Ho <= 0 || d->Wo <= 0)
+    return 0;
+  return plan_wgrad(d).total;
+}
+
+extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* dy,
+                                  float* dw, float* db, void* workspace,
+                                  size_t workspace_bytes, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(d != nullptr, MXDET_EINVAL, "conv2d_wgrad: null descriptor");
+  MXDET_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 &&
+                    d->stride > 0 && d->pad >= 0,
+                MXDET_ESHAPE, "conv2d_wgrad: non-positive dimension");
+  MXDET_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 &&
+                    d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                MXDET_ESHAPE, "conv2d_wgrad: Ho/Wo do not match the convolution arithmetic");
+  MXDET_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, MXDET_ESHAPE,
+                "conv2d_wgrad: Cin and Cout must be multiples of 8");
+  MXDET_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1ll << 31) &&
+                    (long long)d->N * d->Ho * d->Wo * d->Cout < (1ll << 31),
+                MXDET_ESHAPE, "conv2d_wgrad: tensor exceeds 2^31 elements");
+  MXDET_REQUIRE(x && dy && dw, MXDET_EINVAL, "conv2d_wgrad: null pointer");
+  WgradPlan w = plan_wgrad(d);
+  MXDET_REQUIRE(workspace && workspace_bytes >= w.total, MXDET_EWORKSPACE,
+                "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, w.total);
+  MXDET_REQUIRE(!db || d->Cout <= 2048, MXDET_ESHAPE, "conv2d_wgrad: bias gradient supports Cout <= 2048");
+  hipStream_t s = as_stream(stream);
+  WgradP p;
+  p.x = x; p.dy = dy; p.slab = (float*)workspace;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.M = d->N * d->Ho * d->Wo;
+  p.co_tiles = w.co_tiles; p.ci_tiles = w.ci_tiles; p.ksplit = w.ksplit;
+  p.steps_per_split = w.steps_per_split;
+  long long nwg = (long long)w.co_tiles * w.ci_tiles * w.taps * w.ksplit;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+  long long params = (long long)d->Cout * w.taps * d->Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div<long long>(params / 4, 256)), dim3(256),
+                     0, s, (const float*)workspace, w.ksplit, params, d->accumulate, dw);
+  if (db) {
+    float* partial = (float*)((char*)workspace + w.colsum_off);
+    int CG = d->Cout / 8;
+    int RL = 256 / CG > 0 ? 256 / CG : 1;
+    MXDET_REQUIRE(CG <= 256, MXDET_ESHAPE, "conv2d_wgrad: bias gradient supports Cout <= 2048");
+    size_t lds = (size_t)RL * d->Cout * sizeof(float);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(w.colsum_blocks), dim3(256), lds, s, dy, p.M, d->Cout,
+                       w.colsum_rows, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d->Cout, 256)), dim3(256), 0, s,
+                       (const float*)partial, w.colsum_blocks, d->Cout, d->accumulate, db);
+  }
+  return check_launch("conv2d_wgrad");
+}
+
+extern "C" int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW,
+                                      int32_t Cin, uint16_t* wt, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(Cout > 0 && KH > 0 && KW > 0 && Cin > 0, MXDET_ESHAPE, "filter_transpose: bad shape");
+  MXDET_REQUIRE(w && wt, MXDET_EINVAL, "filter_transpose: null pointer");
+  dim3 grid(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW);
+  hipLaunchKernelGGL(filter_transpose_kernel, grid, dim3(32, 8), 0, as_stream(stream), w, Cout, KH * KW,
+                     Cin, wt);
+  return check_launch("filter_transpose");
+}

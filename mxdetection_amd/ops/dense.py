@@ -1,0 +1,172 @@
+"""Dense operators (MXNet roles: Convolution, FullyConnected, Pooling, UpSampling, sgd_mom_update) over the
+HIP C-ABI. Tensors are torch CUDA tensors used purely as device memory: bf16 channels-last [N,H,W,C]
+activations, bf16 [Cout,KH,KW,Cin] filters, fp32 gradients."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import ConvDescT, check, ptr, stream_ptr
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=False, accumulate=False):
+    d = ConvDescT()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = N, H, W, Cin, Cout, KH, KW, stride, pad
+    d.Ho = (H + 2 * pad - KH) // stride + 1
+    d.Wo = (W + 2 * pad - KW) // stride + 1
+    d.relu, d.res_upsample, d.accumulate = int(relu), int(res_upsample), int(accumulate)
+    return d
+
+
+def conv2d_forward(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None):
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_upsample)
+    if out is None:
+        out = torch.empty((N, d.Ho, d.Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), stream_ptr()),
+          "conv2d_fwd")
+    return out
+
+
+def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None):
+    """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter)."""
+    lib = _lib.load()
+    N, H, W, Cin = x_shape
+    Cout = dy.shape[3]
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate)
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
+    check(lib.mxdet_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(residual), ptr(relu_mask), ptr(out), stream_ptr()),
+          "conv2d_dgrad")
+    return out
+
+
+def conv2d_wgrad_workspace_bytes(x_shape, Cout, KH, KW, stride, pad):
+    N, H, W, Cin = x_shape
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    return _lib.load().mxdet_conv2d_wgrad_workspace_bytes(C.byref(d))
+
+
+def conv2d_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=False, workspace=None):
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, accumulate=accumulate)
+    need = lib.mxdet_conv2d_wgrad_workspace_bytes(C.byref(d))
+    if workspace is None:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=x.device)
+    if dw is None:
+        dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
+    check(lib.mxdet_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(workspace), workspace.numel(),
+                                 stream_ptr()), "conv2d_wgrad")
+    return dw
+
+
+def filter_transpose(w, out=None):
+    lib = _lib.load()
+    Cout, KH, KW, Cin = w.shape
+    if out is None:
+        out = torch.empty((Cin, KH, KW, Cout), dtype=torch.bfloat16, device=w.device)
+    check(lib.mxdet_filter_transpose(ptr(w), Cout, KH, KW, Cin, ptr(out), stream_ptr()), "filter_transpose")
+    return out
+
+
+def stem_conv7x7(image, w, bias=None, out=None):
+    """image: NCHW [N,3,H,W] f32|bf16; w bf16 [64,7,7,3]; returns bf16 [N,Ho,Wo,64] (conv + bias + ReLU)."""
+    lib = _lib.load()
+    N, _, H, W = image.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, 64), dtype=torch.bfloat16, device=image.device)
+    check(lib.mxdet_stem_conv7x7(ptr(image), _DT[image.dtype], N, H, W, ptr(w), ptr(bias), ptr(out), stream_ptr()),
+          "stem_conv7x7")
+    return out
+
+
+def maxpool3x3s2(x, out=None):
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cc), dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_maxpool3x3s2(ptr(x), N, H, W, Cc, ptr(out), stream_ptr()), "maxpool3x3s2")
+    return out
+
+
+def subsample2(x, out=None):
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cc), dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_subsample2(ptr(x), N, H, W, Cc, ptr(out), stream_ptr()), "subsample2")
+    return out
+
+
+def subsample2_backward(dy, dx, accumulate=False):
+    lib = _lib.load()
+    N, H, W, Cc = dx.shape
+    check(lib.mxdet_subsample2_bwd(ptr(dy), N, H, W, Cc, int(accumulate), ptr(dx), stream_ptr()), "subsample2_bwd")
+    return dx
+
+
+def upsample2_backward(dfine, dcoarse, accumulate=False):
+    lib = _lib.load()
+    N, Hf, Wf, Cc = dfine.shape
+    check(lib.mxdet_upsample2_bwd(ptr(dfine), N, Hf, Wf, Cc, int(accumulate), ptr(dcoarse), stream_ptr()),
+          "upsample2_bwd")
+    return dcoarse
+
+
+def add_bf16(a, b, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.mxdet_add_bf16(ptr(a), ptr(b), a.numel(), ptr(out), stream_ptr()), "add_bf16")
+    return out
+
+
+def relu_backward(dy, y, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(dy)
+    check(lib.mxdet_relu_bwd_bf16(ptr(dy), ptr(y), dy.numel(), ptr(out), stream_ptr()), "relu_bwd_bf16")
+    return out
+
+
+def f32_to_bf16(x, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_f32_to_bf16(ptr(x), x.numel(), ptr(out), stream_ptr()), "f32_to_bf16")
+    return out
+
+
+def f32_accum_to_bf16(x, y, accumulate):
+    check(_lib.load().mxdet_f32_accum_to_bf16(ptr(x), x.numel(), int(accumulate), ptr(y), stream_ptr()),
+          "f32_accum_to_bf16")
+    return y
+
+
+def nchw_to_nhwc(x):
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, H, W, Cc), dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_nchw_to_nhwc_bf16(ptr(x), _DT[x.dtype], N, Cc, H, W, ptr(out), stream_ptr()), "nchw_to_nhwc_bf16")
+    return out
+
+
+def nhwc_to_nchw(x):
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(lib.mxdet_nhwc_to_nchw_f32(ptr(x), N, Cc, H, W, ptr(out), stream_ptr()), "nhwc_to_nchw_f32")
+    return out
+
+
+def sgd_momentum_update(w, grad, mom, w_bf16, lr, momentum=0.9, wd=1e-4, rescale=1.0):
+    check(_lib.load().mxdet_sgd_momentum_update(ptr(w), ptr(grad), ptr(mom), ptr(w_bf16), w.numel(), lr, momentum, wd,
+                                                rescale, stream_ptr()), "sgd_momentum_update")

@@ -1,0 +1,224 @@
+"""GPU parity tests for the MFMA dense path (conv fwd / dgrad / wgrad, stem, pooling, optimizer).
+
+Floating point: bf16 operands, fp32 MFMA accumulation whose internal order differs from any CPU sum, so
+these are tolerance tests. Tolerances (stated per assert): outputs stored as bf16 carry 2^-9 relative
+rounding; the check is  |got - ref| <= 2^-7 * |ref| + 2^-7 * rms(ref)  elementwise, against two
+independent references: the C oracle (double accumulation, small cases) and torch-CPU fp32 conv.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, what=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    rms = np.sqrt(np.mean(ref ** 2)) + 1e-30
+    err = np.abs(got - ref)
+    bound = 2.0 ** -7 * np.abs(ref) + 2.0 ** -7 * rms
+    bad = err > bound
+    assert not bad.any(), "%s: %d/%d outside tolerance, max err %.4g (rms %.4g)" % (what, bad.sum(), bad.size, err.max(), rms)
+
+
+def _bf(rng, shape, scale=1.0, oracle=None):
+    return oracle.round_bf16((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _t(a, dt=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dt is None else t.to(dt)
+
+
+def _torch_conv(x, w, stride, pad):
+    import torch
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(0, 3, 1, 2),
+                                   stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+CASES = [
+    # N, H, W, Cin, Cout, K, stride, pad
+    (2, 13, 21, 64, 64, 1, 1, 0),
+    (1, 25, 42, 64, 256, 3, 1, 1),
+    (2, 26, 43, 128, 128, 3, 2, 1),
+    (1, 50, 84, 256, 512, 1, 2, 0),
+    (2, 9, 11, 512, 136, 3, 1, 1),     # Cout not a multiple of the 128 tile
+    (1, 14, 14, 256, 16, 1, 1, 0),     # RPN head output (5A padded to 16)
+    (3, 1, 1, 12544, 1024, 1, 1, 0),   # FC as 1x1 conv (M = 3 rows: mostly padding)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd(hip, oracle, case):
+    import torch
+    from mxdetection_amd.ops import dense
+    N, H, W, Cin, Cout, K, s, p = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+    w = _bf(rng, (Cout, K, K, Cin), (2.0 / (K * K * Cin)) ** 0.5, oracle)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    y = dense.conv2d_forward(_t(x, torch.bfloat16), _t(w, torch.bfloat16), _t(bias), None, s, p, relu=True)
+    ref = np.maximum(_torch_conv(x, w, s, p) + bias, 0)
+    _close(y.float().cpu().numpy(), ref, "fwd vs torch")
+    if N * H * W * Cin * Cout * K * K < 3e9:
+        _close(y.float().cpu().numpy(), oracle.conv2d_fwd(x, w, bias, None, s, p, True), "fwd vs oracle")
+    # residual add (same shape) without ReLU
+    res = _bf(rng, ref.shape, 1.0, oracle)
+    y2 = dense.conv2d_forward(_t(x, torch.bfloat16), _t(w, torch.bfloat16), None, _t(res, torch.bfloat16), s, p)
+    _close(y2.float().cpu().numpy(), _torch_conv(x, w, s, p) + res, "fwd+res")
+
+
+def test_conv_fwd_upsampled_residual(hip, oracle):
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(3)
+    x = _bf(rng, (2, 25, 42, 128), 1.0, oracle)
+    w = _bf(rng, (64, 1, 1, 128), 0.1, oracle)
+    coarse = _bf(rng, (2, 13, 21, 64), 1.0, oracle)
+    y = dense.conv2d_forward(_t(x, torch.bfloat16), _t(w, torch.bfloat16), None, _t(coarse, torch.bfloat16), 1, 0,
+                             res_upsample=True)
+    ref = oracle.conv2d_fwd(x, w, None, coarse, 1, 0, False, True)
+    _close(y.float().cpu().numpy(), ref, "lateral + top-down")
+
+
+@pytest.mark.parametrize("case", CASES[:6])
+def test_conv_dgrad(hip, oracle, case):
+    import torch
+    from mxdetection_amd.ops import dense
+    N, H, W, Cin, Cout, K, s, p = case
+    if Cout % 64:
+        pytest.skip("dgrad reduces over Cout: needs a multiple of 64")
+    rng = np.random.default_rng(7)
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    dy = _bf(rng, (N, Ho, Wo, Cout), 1.0, oracle)
+    w = _bf(rng, (Cout, K, K, Cin), (2.0 / (K * K * Cout)) ** 0.5, oracle)
+    wt = dense.filter_transpose(_t(w, torch.bfloat16))
+    assert torch.equal(wt.cpu(), torch.from_numpy(w).to(torch.bfloat16).permute(3, 1, 2, 0).contiguous())
+    dx = dense.conv2d_dgrad(_t(dy, torch.bfloat16), wt, (N, H, W, Cin), K, K, s, p)
+    xt = torch.zeros((N, Cin, H, W), requires_grad=True)
+    yt = torch.nn.functional.conv2d(xt, torch.from_numpy(w).permute(0, 3, 1, 2), stride=s, padding=p)
+    yt.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    _close(dx.float().cpu().numpy(), ref, "dgrad vs torch")
+    if N * H * W * Cin * Cout * K * K < 3e9:
+        _close(dx.float().cpu().numpy(), oracle.conv2d_dgrad(dy, w, (N, H, W, Cin), s, p), "dgrad vs oracle")
+    # residual branch + ReLU mask: dx = (dgrad + res) * (x > 0)
+    res = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+    act = np.maximum(_bf(rng, (N, H, W, Cin), 1.0, oracle), 0)
+    dx2 = dense.conv2d_dgrad(_t(dy, torch.bfloat16), wt, (N, H, W, Cin), K, K, s, p, residual=_t(res, torch.bfloat16),
+                             relu_mask=_t(act, torch.bfloat16))
+    _close(dx2.float().cpu().numpy(), (ref + res) * (act > 0), "dgrad+res+mask")
+    # accumulate into an existing gradient
+    dx3 = _t(res, torch.bfloat16).clone()
+    dense.conv2d_dgrad(_t(dy, torch.bfloat16), wt, (N, H, W, Cin), K, K, s, p, accumulate=True, out=dx3)
+    _close(dx3.float().cpu().numpy(), ref + res, "dgrad accumulate")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wgrad(hip, oracle, case):
+    import torch
+    from mxdetection_amd.ops import dense
+    N, H, W, Cin, Cout, K, s, p = case
+    rng = np.random.default_rng(11)
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    x = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+    dy = _bf(rng, (N, Ho, Wo, Cout), 1.0, oracle)
+    db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
+    dw = dense.conv2d_wgrad(_t(x, torch.bfloat16), _t(dy, torch.bfloat16), K, K, s, p, db=db)
+    wtorch = torch.zeros((Cout, Cin, K, K), requires_grad=True)
+    yt = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), wtorch, stride=s, padding=p)
+    yt.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    ref = wtorch.grad.permute(0, 2, 3, 1).numpy()
+    got = dw.cpu().numpy()
+    # fp32 output: only accumulation-order error, 1e-4 of the tensor's rms
+    rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    assert np.abs(got - ref).max() <= 2e-4 * rms + 1e-5 * np.abs(ref).max(), np.abs(got - ref).max()
+    assert np.allclose(db.cpu().numpy(), dy.reshape(-1, Cout).sum(0), rtol=1e-4, atol=1e-3)
+    # deterministic: a second run is bit-identical; accumulate doubles it
+    dw2 = dense.conv2d_wgrad(_t(x, torch.bfloat16), _t(dy, torch.bfloat16), K, K, s, p)
+    assert torch.equal(dw, dw2)
+    dense.conv2d_wgrad(_t(x, torch.bfloat16), _t(dy, torch.bfloat16), K, K, s, p, dw=dw2, accumulate=True)
+    assert torch.allclose(dw2, 2 * dw)
+
+
+def test_conv_wgrad_large_splitk(hip, oracle):
+    """P3-sized 3x3 layer: many split-K slabs, compared with torch-CPU."""
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(13)
+    N, H, W, Cin, Cout = 2, 100, 168, 256, 256
+    x = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+    dy = _bf(rng, (N, H, W, Cout), 0.1, oracle)
+    dw = dense.conv2d_wgrad(_t(x, torch.bfloat16), _t(dy, torch.bfloat16), 3, 3, 1, 1)
+    wtorch = torch.zeros((Cout, Cin, 3, 3), requires_grad=True)
+    torch.set_num_threads(8)
+    yt = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), wtorch, padding=1)
+    yt.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    ref = wtorch.grad.permute(0, 2, 3, 1).numpy()
+    rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    assert np.abs(dw.cpu().numpy() - ref).max() <= 1e-3 * rms
+
+
+def test_stem_and_maxpool(hip, oracle):
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(17)
+    N, H, W = 2, 75, 333
+    img = rng.standard_normal((N, 3, H, W)).astype(np.float32)
+    w = _bf(rng, (64, 7, 7, 3), (2.0 / 147) ** 0.5, oracle)
+    bias = rng.standard_normal(64).astype(np.float32) * 0.1
+    y = dense.stem_conv7x7(_t(img), _t(w, torch.bfloat16), _t(bias))
+    xr = oracle.round_bf16(img).transpose(0, 2, 3, 1).copy()
+    ref = np.maximum(_torch_conv(xr, w, 2, 3) + bias, 0)
+    assert tuple(y.shape) == ref.shape
+    _close(y.float().cpu().numpy(), ref, "stem")
+    yb = dense.stem_conv7x7(_t(img, torch.bfloat16), _t(w, torch.bfloat16), _t(bias))
+    assert torch.equal(y, yb)
+    # max pooling is exact
+    pooled = dense.maxpool3x3s2(y)
+    want = oracle.maxpool3x3s2(y.float().cpu().numpy())
+    assert np.array_equal(pooled.float().cpu().numpy(), want)
+
+
+def test_resampling_and_elementwise(hip, oracle):
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(19)
+    x = _t(_bf(rng, (2, 25, 42, 64), 1.0, oracle), torch.bfloat16)
+    sub = dense.subsample2(x)
+    assert torch.equal(sub, x[:, ::2, ::2, :])
+    dxs = torch.ones_like(x)
+    dense.subsample2_backward(sub, dxs, accumulate=True)
+    want = torch.ones_like(x).float()
+    want[:, ::2, ::2, :] += sub.float()
+    assert torch.equal(dxs.float(), want.to(torch.bfloat16).float())
+    fine = _t(_bf(rng, (2, 25, 42, 64), 1.0, oracle), torch.bfloat16)
+    coarse = torch.zeros((2, 13, 21, 64), dtype=torch.bfloat16, device="cuda")
+    dense.upsample2_backward(fine, coarse)
+    f = torch.nn.functional.pad(fine.float(), (0, 0, 0, 0, 0, 1))     # H 25 -> 26
+    ref = f.view(2, 13, 2, 21, 2, 64).sum((2, 4))
+    assert torch.allclose(coarse.float(), ref, rtol=2 ** -7, atol=2 ** -7)
+    a, b = x, fine
+    assert torch.equal(dense.add_bf16(a, b).float(), (a.float() + b.float()).to(torch.bfloat16).float())
+    assert torch.equal(dense.relu_backward(a, b), torch.where(b > 0, a, torch.zeros_like(a)))
+    f32 = torch.randn(1000003, device="cuda")
+    assert torch.equal(dense.f32_to_bf16(f32), f32.to(torch.bfloat16))
+    img = torch.randn(2, 5, 7, 9, device="cuda")
+    nhwc = dense.nchw_to_nhwc(img)
+    assert torch.equal(nhwc, img.permute(0, 2, 3, 1).to(torch.bfloat16))
+    assert torch.equal(dense.nhwc_to_nchw(nhwc), nhwc.float().permute(0, 3, 1, 2))
+
+
+def test_sgd_momentum(hip):
+    import torch
+    from mxdetection_amd.ops import dense
+    n = 1000003
+    w, g, m = torch.randn(n, device="cuda"), torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    wb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    w0, m0 = w.clone(), m.clone()
+    dense.sgd_momentum_update(w, g, m, wb, 0.02, 0.9, 1e-4, 0.5)
+    m_ref = 0.9 * m0 + (g * 0.5 + 1e-4 * w0)
+    w_ref = w0 - 0.02 * m_ref
+    assert torch.allclose(m, m_ref, rtol=1e-6, atol=1e-7) and torch.allclose(w, w_ref, rtol=1e-6, atol=1e-7)
+    assert torch.equal(wb, w.to(torch.bfloat16))
