@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the Faster R-CNN R50-FPN training step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the gradient buckets)
+
+A step = forward + RPN/RCNN targets + losses + explicit backward + gradient all-reduce + SGD-momentum update on
+a synthetic batch of 2 images of 3x800x1333 (zero-padded to 1344) per GPU, inputs resident in HBM.
+Prints ONE JSON line (rank 0). See DESIGN.md section 7 for what each field means.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 2
+IM_H, IM_W, PAD_W = 800, 1333, 1344
+G_MAX = 100
+# algorithmic conv-GEMM work per image: fwd 201.6 GMAC; training with conv1+C2 frozen
+TRAIN_CONV_FLOP_PER_IMAGE = 1.142e12
+MFMA_PEAK_BF16 = 2.5e15
+
+
+def synth_batch(rank, step, device):
+    """SURVEY.md section 8d synthetic inputs."""
+    import torch
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.zeros((BATCH_PER_GPU, 3, IM_H, PAD_W), dtype=torch.float32)
+    img[..., :IM_W] = torch.randn((BATCH_PER_GPU, 3, IM_H, IM_W), generator=g)
+    rng = np.random.default_rng(4321 + rank * 1000 + step)
+    gt = -np.ones((BATCH_PER_GPU, G_MAX, 5), np.float32)
+    for n in range(BATCH_PER_GPU):
+        G = int(rng.integers(4, 17))
+        for k in range(G):
+            w = min(float(np.exp(rng.uniform(np.log(16), np.log(600)))), IM_W - 1)
+            h = min(float(np.exp(rng.uniform(np.log(16), np.log(600)))), IM_H - 1)
+            x1, y1 = float(rng.uniform(0, IM_W - w)), float(rng.uniform(0, IM_H - h))
+            gt[n, k] = [x1, y1, x1 + w - 1, y1 + h - 1, float(rng.integers(1, 81))]
+    im_info = torch.tensor([[IM_H, IM_W, 1.0]] * BATCH_PER_GPU, dtype=torch.float32)
+    return img.to(device), torch.from_numpy(gt).to(device), im_info.to(device)
+
+
+class ConvTimer:
+    """Times every conv launch of the timed region with HIP events on the launch stream and attributes
+    algorithmic FLOPs to it (2 * M * Ncols * K per launch). Used for the `roofline` object."""
+
+    def __init__(self):
+        self.records = []   # (family, flops, start_event, end_event)
+        self.enabled = False
+
+    def install(self):
+        import torch
+        from mxdetection_amd.ops import dense
+        timer = self
+
+        def wrap(fn, family, flops_of):
+            def inner(*a, **kw):
+                if not timer.enabled:
+                    return fn(*a, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = fn(*a, **kw)
+                e.record()
+                timer.records.append((family, flops_of(*a, **kw), s, e))
+                return out
+            return inner
+
+        def f_fwd(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None):
+            N, H, W, Cin = x.shape
+            Cout, KH, KW, _ = w.shape
+            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+            return 2.0 * N * Ho * Wo * Cout * KH * KW * Cin
+
+        def f_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None):
+            N, Ho, Wo, Cout = dy.shape
+            return 2.0 * N * Ho * Wo * Cout * KH * KW * x_shape[3]
+
+        def f_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=False, workspace=None):
+            N, Ho, Wo, Cout = dy.shape
+            return 2.0 * N * Ho * Wo * Cout * KH * KW * x.shape[3]
+
+        dense.conv2d_forward = wrap(dense.conv2d_forward, "conv_igemm_fwd", f_fwd)
+        dense.conv2d_dgrad = wrap(dense.conv2d_dgrad, "conv_igemm_dgrad", f_dgrad)
+        dense.conv2d_wgrad = wrap(dense.conv2d_wgrad, "conv_wgrad", f_wgrad)
+
+    def summary(self):
+        fam = {}
+        for family, flops, s, e in self.records:
+            t = s.elapsed_time(e) * 1e-3
+            a = fam.setdefault(family, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += t
+            a[2] += 1
+        return fam
+
+
+def cpu_baseline(rank):
+    """Bounded CPU leg: the oracle-side torch-CPU/C restatement of the same step on ONE 3x800x1333 image."""
+    try:
+        from oracle import model_ref
+    except Exception as ex:  # noqa: BLE001
+        return {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "unavailable: %r" % (ex,)}
+    return model_ref.timed_cpu_baseline()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-timer", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    device = "cuda"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+
+    from mxdetection_amd.models import FasterRCNN
+    timer = ConvTimer()
+    if not args.no_conv_timer:
+        timer.install()
+    model = FasterRCNN(device, depth=50, seed=7)
+    if world > 1:
+        model.enable_data_parallel(world)
+        dist.broadcast(model.arena.w, 0)
+        model.arena.refresh_bf16()
+        model.refresh_transposed()
+    lr = 0.02 * (BATCH_PER_GPU * world) / 16.0
+    batches = [synth_batch(rank, s, device) for s in range(4)]
+
+    def step(i):
+        img, gt, info = batches[i % len(batches)]
+        return model.train_step(img, gt, info, step=i, image_offset=rank * BATCH_PER_GPU, lr=lr)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = not args.no_conv_timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_vals = [float(v) for v in torch.cat(losses).cpu().numpy()]
+
+    if rank == 0:
+        images = args.steps * BATCH_PER_GPU * world
+        value = images / dt
+        per_gpu = value / world
+        fam = timer.summary()
+        roofline = None
+        families = {}
+        if fam:
+            dom = max(fam.items(), key=lambda kv: kv[1][1])
+            for k, (fl, tt, n) in fam.items():
+                families[k] = {"launches": n, "avg_ms": round(1e3 * tt / max(n, 1), 4), "tflops": round(fl / tt / 1e12, 1),
+                               "share_of_step": round(tt / dt, 3)}
+            fl, tt, n = dom[1]
+            roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(fl / tt / 1e12, 2), "peak": 2500.0,
+                        "unit": "TFLOP/s", "frac": round(fl / tt / MFMA_PEAK_BF16, 4), "traffic": None,
+                        "launches": n, "avg_launch_ms": round(1e3 * tt / n, 4)}
+        out = {
+            "metric": "images/sec (whole node) Faster R-CNN R50-FPN 3x800x1333",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Faster R-CNN ResNet-50-FPN bf16 train step, batch 2/GPU, 3x800x1333 (padded 1344)",
+                       "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
+                       "frozen": "stem+C2, frozen BN folded", "optimizer": "SGD momentum 0.9 wd 1e-4",
+                       "params_trainable": model.num_params()},
+            "model_mfma_roofline_frac": round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4),
+            "losses_last_step": {"rpn_cls": loss_vals[0], "rpn_reg": loss_vals[1], "rcnn_cls": loss_vals[2],
+                                 "rcnn_reg": loss_vals[3]},
+            "roofline": roofline,
+            "conv_families": families,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rank)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""ResNet-50/101 backbone ("v1b": the stride sits on the 3x3 conv) with frozen BatchNorm folded into the
+filters, frozen stem + C2 (forward only), explicit backward through C5..C3.
+
+Plugin slot: models/backbones (/root/reference/README.md:27). MXNet roles replaced: Convolution,
+BatchNorm(use_global_stats=True), Activation, Pooling, elemwise_add (README.md:37) - here every bottleneck
+conv is ONE kernel with the BN shift, the residual add and the ReLU fused into its epilogue, and every
+backward ReLU / shortcut add is fused into a dgrad epilogue.
+"""
+import torch
+
+from ...ops import dense
+from ..utils.layers import ConvLayer
+
+
+class Bottleneck:
+    def __init__(self, name, cin, planes, stride, downsample, trainable, need_dx, arena, ws, device, gen):
+        kw = dict(arena=arena, ws=ws, device=device, gen=gen, trainable=trainable, train_bias=False)
+        self.trainable, self.need_dx = trainable, need_dx
+        # registered in backward completion order: conv3, conv2, conv1 / downsample
+        self.conv3 = ConvLayer(name + ".conv3", planes, planes * 4, 1, **kw)
+        self.conv2 = ConvLayer(name + ".conv2", planes, planes, 3, stride, **kw)
+        self.conv1 = ConvLayer(name + ".conv1", cin, planes, 1, **kw)
+        self.down = ConvLayer(name + ".down", cin, planes * 4, 1, stride, 0, **kw) if downsample else None
+        self.x = self.a1 = self.a2 = self.y = self.sc = None
+        self.bufs = {}
+
+    def layers(self):
+        return [l for l in (self.conv3, self.conv2, self.conv1, self.down) if l is not None]
+
+    def _buf(self, key, shape):
+        b = self.bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = torch.empty(shape, dtype=torch.bfloat16, device=self.conv1.device)
+            self.bufs[key] = b
+        return b
+
+    def plan(self, x_shape):
+        s1 = self.conv1.out_shape(x_shape)
+        s2 = self.conv2.out_shape(s1)
+        self.conv1.plan(x_shape)
+        self.conv2.plan(s1)
+        self.conv3.plan(s2)
+        if self.down is not None:
+            self.down.plan(x_shape)
+        return self.conv3.out_shape(s2)
+
+    def forward(self, x):
+        self.x = x
+        self.a1 = self.conv1.forward(x, relu=True, out=self._buf("a1", self.conv1.out_shape(x.shape)))
+        self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", self.conv2.out_shape(self.a1.shape)))
+        oshape = self.conv3.out_shape(self.a2.shape)
+        sc = x if self.down is None else self.down.forward(x, out=self._buf("sc", oshape))
+        self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape))
+        return self.y
+
+    def backward(self, ds, dx_buf, dx_has_grad):
+        """ds: gradient w.r.t. the pre-activation sum (already masked by y > 0).
+
+        dx_buf receives d(loss)/d(pre-activation of the producer of x), i.e. the total gradient arriving at x
+        masked by (x > 0); if dx_has_grad it already holds a partial gradient (FPN lateral) to add to.
+        """
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        c3.backward_weight(self.a2, ds)
+        d_a2 = c3.backward_data(ds, self.a2.shape, relu_mask=self.a2, out=self._buf("d_a2", self.a2.shape))
+        c2.backward_weight(self.a1, d_a2)
+        d_a1 = c2.backward_data(d_a2, self.a1.shape, relu_mask=self.a1, out=self._buf("d_a1", self.a1.shape))
+        c1.backward_weight(self.x, d_a1)
+        if self.down is not None:
+            self.down.backward_weight(self.x, ds)
+        if not self.need_dx:
+            return None
+        if self.down is not None:
+            self.down.backward_data(ds, self.x.shape, accumulate=dx_has_grad, out=dx_buf)
+            c1.backward_data(d_a1, self.x.shape, residual=dx_buf, relu_mask=self.x, out=dx_buf)
+        else:
+            if dx_has_grad:
+                dense.add_bf16(dx_buf, ds, dx_buf)
+                c1.backward_data(d_a1, self.x.shape, residual=dx_buf, relu_mask=self.x, out=dx_buf)
+            else:
+                c1.backward_data(d_a1, self.x.shape, residual=ds, relu_mask=self.x, out=dx_buf)
+        return dx_buf
+
+
+class ResNet:
+    """depth 50: (3,4,6,3), depth 101: (3,4,23,3). Returns C2..C5 (bf16 channels-last)."""
+
+    def __init__(self, depth, arena, ws, device, gen, frozen_stages=1):
+        blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+        self.device = device
+        # registration order == backward completion order: layer4 ... layer2 (layer1 + stem frozen)
+        self.stages = [None] * 4
+        cins = [64, 256, 512, 1024]
+        for si in (3, 2, 1, 0):
+            planes = 64 << si
+            trainable = si > frozen_stages - 1 and si >= 1 if frozen_stages >= 1 else True
+            stage = []
+            for bi in reversed(range(blocks[si])):
+                cin = cins[si] if bi == 0 else planes * 4
+                stride = 2 if (bi == 0 and si > 0) else 1
+                need_dx = trainable and not (bi == 0 and (si == 0 or si - 1 < frozen_stages))
+                stage.insert(0, Bottleneck("layer%d.%d" % (si + 1, bi), cin, planes, stride, bi == 0, trainable,
+                                           need_dx, arena, ws, device, gen))
+            self.stages[si] = stage
+        self.stem_w = (torch.randn((64, 7, 7, 3), generator=gen) * (2.0 / 147) ** 0.5).to(torch.bfloat16).to(device)
+        self.stem_b = torch.zeros((64,), dtype=torch.float32, device=device)
+        self.bufs = {}
+        self.outs = None
+
+    def layers(self):
+        return [l for st in self.stages for b in st for l in b.layers()]
+
+    def plan(self, image_shape):
+        N, _, H, W = image_shape
+        s = (N, ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1, 64)
+        shapes = []
+        for st in self.stages:
+            for b in st:
+                s = b.plan(s)
+            shapes.append(s)
+        return shapes
+
+    def forward(self, image):
+        """image: NCHW [N,3,H,W] (f32 or bf16), read directly by the stem kernel."""
+        x = dense.stem_conv7x7(image, self.stem_w, self.stem_b, self.bufs.get("stem"))
+        self.bufs["stem"] = x
+        x = dense.maxpool3x3s2(x, self.bufs.get("pool"))
+        self.bufs["pool"] = x
+        outs = []
+        for st in self.stages:
+            for b in st:
+                x = b.forward(x)
+            outs.append(x)
+        self.outs = outs
+        return outs
+
+    def backward(self, dC):
+        """dC[i]: bf16 buffer holding the FPN-lateral gradient w.r.t. C(i+2) (un-masked) for i = 1..3 (C3..C5);
+        dC[3] (C5) must already be masked by (C5 > 0). Walks layer4 -> layer2."""
+        for si in (3, 2, 1):
+            stage = self.stages[si]
+            if not stage[0].trainable:
+                break
+            ds = dC[si]
+            for bi in reversed(range(len(stage))):
+                b = stage[bi]
+                if bi > 0:
+                    dxb = b._buf("dx", b.x.shape)
+                    ds = b.backward(ds, dxb, False)
+                else:
+                    # input of the stage's first block is the previous stage's output: add to its lateral gradient
+                    if b.need_dx:
+                        ds = b.backward(ds, dC[si - 1], True)
+                    else:
+                        b.backward(ds, None, False)

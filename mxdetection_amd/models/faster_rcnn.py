@@ -1,0 +1,137 @@
+"""Faster R-CNN ResNet-FPN: one training step = forward, targets, losses, explicit backward, gradient
+all-reduce (RCCL, overlapped with backward), SGD-momentum update. Every arithmetic step is a hand-written
+HIP kernel reached through the C-ABI; torch supplies device memory, streams and torch.distributed only.
+
+Assembles the plugin parts the reference declares (/root/reference/README.md:27-32). The training loop
+itself is not declared anywhere in the reference tree; this is the build's own.
+"""
+import torch
+
+from .backbones import ResNet
+from .bbox_heads import BBoxHead
+from .necks import FPN
+from .roi_extractors import FPNRoIExtractor
+from .rpn_heads import RPNHead
+from .utils.layers import ParamArena, Workspace
+
+
+class FasterRCNN:
+    def __init__(self, device="cuda", depth=50, num_classes=81, seed=7, rpn_seed=99, rois_per_image=512,
+                 pre_nms_top_n=2000, post_nms_top_n=2000):
+        gen = torch.Generator().manual_seed(seed)
+        self.device = device
+        self.arena = ParamArena(device)
+        self.ws = Workspace(device)
+        self.strides = [4, 8, 16, 32, 64]
+        # registration order == backward completion order (buckets become final early)
+        self.bbox_head = BBoxHead(7 * 7 * 256, self.arena, self.ws, device, gen, num_classes=num_classes,
+                                  rois_per_image=rois_per_image, seed=rpn_seed)
+        self.mark_head = self.arena.size
+        self.rpn_head = RPNHead(256, self.strides, self.arena, self.ws, device, gen, pre_nms_top_n=pre_nms_top_n,
+                                post_nms_top_n=post_nms_top_n, seed=rpn_seed)
+        self.mark_rpn = self.arena.size
+        self.neck = FPN([256, 512, 1024, 2048], 256, self.arena, self.ws, device, gen)
+        self.mark_fpn = self.arena.size
+        self.backbone = ResNet(depth, self.arena, self.ws, device, gen)
+        self.roi_extractor = FPNRoIExtractor(self.strides[:4], device=device)
+        self.arena.finalize()
+        self.layers = self.bbox_head.layers() + self.rpn_head.layers() + self.neck.layers() + self.backbone.layers()
+        for l in self.layers:
+            l.materialize()
+        self.arena.refresh_bf16()
+        self.refresh_transposed()
+        # arena offsets after each backbone stage (layer4, layer3, layer2) for bucketed all-reduce
+        self.stage_marks = {}
+        for si in (3, 2, 1):
+            last = self.backbone.stages[si][0].layers()[-1]
+            e = self.arena.entries[last.wi]
+            self.stage_marks[si] = e[2] + (e[3] + 63) // 64 * 64
+        self.planned = None
+        self.dist = None
+        self.pending = []
+
+    def num_params(self):
+        return sum(e[3] for e in self.arena.entries)
+
+    def refresh_transposed(self):
+        for l in self.layers:
+            l.refresh_transposed()
+
+    def enable_data_parallel(self, world_size):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = world_size
+
+    def plan(self, N, H, W, g_max):
+        key = (N, H, W, g_max)
+        if self.planned == key:
+            return
+        dev = self.device
+        c_shapes = self.backbone.plan((N, 3, H, W))
+        self.neck.plan(c_shapes)
+        p_shapes = [(s[0], s[1], s[2], 256) for s in c_shapes]
+        p_shapes.append((N, (p_shapes[-1][1] + 1) // 2, (p_shapes[-1][2] + 1) // 2, 256))
+        self.rpn_head.plan(p_shapes, g_max)
+        self.bbox_head.plan(N)
+        self.ws.get()
+        self.dP = [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in p_shapes]
+        self.dC = [None] + [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in c_shapes[1:]]
+        self.planned = key
+
+    # ---- gradient buckets -----------------------------------------------------------------------
+    def _reduce(self, lo, hi):
+        if self.dist is not None and hi > lo:
+            self.pending.append(self.dist.all_reduce(self.arena.g[lo:hi], async_op=True))
+
+    def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0):
+        """image NCHW [N,3,H,W]; gt_boxes [N,G,5] f32 (class < 0 padding); im_info [N,3] f32."""
+        N, _, H, W = image.shape
+        self.plan(N, H, W, gt_boxes.shape[1])
+        C = self.backbone.forward(image)
+        P = self.neck.forward(C)
+        self.rpn_head.forward(P)
+        rois, _, _, num_rois = self.rpn_head.get_proposals(im_info)
+        rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset)
+        rois_s = self.bbox_head.sample(rois, num_rois, gt_boxes, step, image_offset)
+        pooled = self.roi_extractor.forward(P, rois_s)
+        self.bbox_head.forward(pooled)
+        rcnn_loss = self.bbox_head.loss_and_grad()
+        # ---- backward ----
+        d_pooled = self.bbox_head.backward()
+        self._reduce(0, self.mark_head)
+        self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4])
+        self.rpn_head.backward(self.dP, [True, True, True, True, False])
+        self._reduce(self.mark_head, self.mark_rpn)
+        self.neck.backward(self.dP, self.dC, [False, True, True, True])
+        self._reduce(self.mark_rpn, self.mark_fpn)
+        lo = self.mark_fpn
+        for si in (3, 2, 1):
+            self._backbone_stage_backward(si)
+            self._reduce(lo, self.stage_marks[si])
+            lo = self.stage_marks[si]
+        return rpn_loss, rcnn_loss
+
+    def _backbone_stage_backward(self, si):
+        stage = self.backbone.stages[si]
+        ds = self.dC[si]
+        for bi in reversed(range(len(stage))):
+            b = stage[bi]
+            if bi > 0:
+                ds = b.backward(ds, b._buf("dx", b.x.shape), False)
+            elif b.need_dx:
+                b.backward(ds, self.dC[si - 1], True)
+            else:
+                b.backward(ds, None, False)
+
+    def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        rescale = 1.0 / self.world if self.dist is not None else 1.0
+        self.arena.sgd_step(lr, momentum, wd, rescale)
+        self.refresh_transposed()
+
+    def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025):
+        losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset)
+        self.optimizer_step(lr)
+        return losses

@@ -1,0 +1,75 @@
+"""Feature Pyramid Network neck: 1x1 laterals, top-down nearest-2x add, 3x3 outputs, P6 = stride-2 subsample.
+
+Plugin slot: models/necks (/root/reference/README.md:31). MXNet roles replaced: Convolution, UpSampling(nearest),
+elemwise_add, Pooling (README.md:37). The top-down add is fused into the lateral conv's epilogue (the coarser map is
+read nearest-neighbour as the residual), so the merged map is written once and never re-read for the add.
+"""
+import torch
+
+from ...ops import dense
+from ..utils.layers import ConvLayer
+
+
+class FPN:
+    def __init__(self, in_channels, out_channels, arena, ws, device, gen, extra_p6=True):
+        kw = dict(arena=arena, ws=ws, device=device, gen=gen)
+        L = len(in_channels)
+        # registered in backward completion order: output convs fine -> coarse, then laterals
+        self.outs = [ConvLayer("fpn.out%d" % (i + 2), out_channels, out_channels, 3, **kw) for i in range(L)]
+        self.lats = [ConvLayer("fpn.lat%d" % (i + 2), in_channels[i], out_channels, 1, **kw) for i in range(L)]
+        self.L, self.C, self.extra_p6 = L, out_channels, extra_p6
+        self.device = device
+        self.bufs = {}
+        self.inner = self.feats = self.P = None
+
+    def layers(self):
+        return self.outs + self.lats
+
+    def plan(self, c_shapes):
+        for i, s in enumerate(c_shapes):
+            self.lats[i].plan(s)
+            self.outs[i].plan((s[0], s[1], s[2], self.C))
+
+    def _buf(self, key, shape):
+        b = self.bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+            self.bufs[key] = b
+        return b
+
+    def forward(self, feats):
+        L = self.L
+        self.feats = feats
+        inner = [None] * L
+        for i in reversed(range(L)):
+            shape = feats[i].shape[:3] + (self.C,)
+            res = inner[i + 1] if i + 1 < L else None
+            inner[i] = self.lats[i].forward(feats[i], residual=res, res_upsample=res is not None,
+                                            out=self._buf("inner%d" % i, shape))
+        P = [self.outs[i].forward(inner[i], out=self._buf("P%d" % i, inner[i].shape)) for i in range(L)]
+        if self.extra_p6:
+            N, H, W, Cc = P[-1].shape
+            P.append(dense.subsample2(P[-1], self._buf("P6", (N, (H + 1) // 2, (W + 1) // 2, Cc))))
+        self.inner, self.P = inner, P
+        return P
+
+    def backward(self, dP, dC, c_needs_grad):
+        """dP[i]: gradient w.r.t. P(i+2) (bf16); dC[i]: output buffers for the gradient w.r.t. C(i+2);
+        c_needs_grad[i] says whether the backbone wants it. The top level's dC is masked by (C > 0) here
+        (the lateral is its only consumer); the others stay un-masked for the backbone to finish."""
+        L = self.L
+        if self.extra_p6:
+            dense.subsample2_backward(dP[L], dP[L - 1], accumulate=True)
+        dinner = [None] * L
+        for i in range(L):
+            self.outs[i].backward_weight(self.inner[i], dP[i])
+            dinner[i] = self.outs[i].backward_data(dP[i], self.inner[i].shape,
+                                                   out=self._buf("dinner%d" % i, self.inner[i].shape))
+            if i > 0:
+                dense.upsample2_backward(dinner[i - 1], dinner[i], accumulate=True)
+        for i in range(L):
+            self.lats[i].backward_weight(self.feats[i], dinner[i])
+            if c_needs_grad[i]:
+                top = i == L - 1
+                self.lats[i].backward_data(dinner[i], self.feats[i].shape, relu_mask=self.feats[i] if top else None,
+                                           out=dC[i])

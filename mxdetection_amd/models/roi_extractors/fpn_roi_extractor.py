@@ -1,0 +1,37 @@
+"""FPN RoI extractor: level = clamp(floor(4 + log2(sqrt(wh)/224)), 2, 5), then one multi-level RoIAlign launch.
+
+Plugin slot: models/roi_extractors (/root/reference/README.md:32); MXNet role contrib.ROIAlign (README.md:37).
+"""
+import torch
+
+from ...ops import dense
+from ...ops.roi_align import fpn_level_map, roi_align_backward, roi_align_forward
+
+
+class FPNRoIExtractor:
+    def __init__(self, strides, pooled=(7, 7), sampling_ratio=2, lvl_min=2, device="cuda"):
+        self.scales = [1.0 / s for s in strides]
+        self.pooled, self.sr, self.lvl_min = pooled, sampling_ratio, lvl_min
+        self.lvl_max = lvl_min + len(strides) - 1
+        self.device = device
+        self.out = None
+        self.dacc = None
+
+    def forward(self, feats, rois):
+        """feats: P2..P5 (bf16 [N,H,W,C]); rois [R,5] f32."""
+        self.feats, self.rois = feats[:len(self.scales)], rois
+        self.levels = fpn_level_map(rois, self.lvl_min, self.lvl_max)
+        R, C = rois.shape[0], feats[0].shape[3]
+        if self.out is None or self.out.shape[0] != R:
+            self.out = torch.empty((R, self.pooled[0], self.pooled[1], C), dtype=torch.bfloat16, device=self.device)
+        return roi_align_forward(self.feats, self.scales, rois, self.levels, self.pooled, self.sr, self.lvl_min, self.out)
+
+    def backward(self, grad_out, dP):
+        """Scatter grad_out into fp32 accumulators, then write them (rounded once) into the bf16 dP[l]."""
+        if self.dacc is None:
+            self.dacc = [torch.empty(f.shape, dtype=torch.float32, device=self.device) for f in self.feats]
+        for a in self.dacc:
+            a.zero_()
+        roi_align_backward(self.dacc, self.scales, self.rois, self.levels, grad_out, self.sr, self.lvl_min)
+        for a, d in zip(self.dacc, dP):
+            dense.f32_accum_to_bf16(a, d, accumulate=False)

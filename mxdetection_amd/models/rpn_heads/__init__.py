@@ -1,0 +1,2 @@
+"""models/rpn_heads (/root/reference/README.md:28)."""
+from .rpn_head import RPNHead  # noqa: F401

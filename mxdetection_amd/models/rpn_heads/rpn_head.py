@@ -1,0 +1,106 @@
+"""Region Proposal Network head over an FPN pyramid: shared 3x3 conv + ReLU, one fused 1x1 conv producing the
+objectness logits (channels 0..A-1) and box deltas (channels A..5A-1), RPN targets + losses, proposal generation.
+
+Plugin slot: models/rpn_heads (/root/reference/README.md:28) with ops (README.md:24) and core/anchor, core/loss
+(README.md:16,19). Everything (targets, sampling, NMS) stays on the GPU; MXNet-lineage code runs these as
+numpy/Cython CustomOps on the host.
+"""
+import torch
+
+from ...core import anchor as A_
+from ...core import loss as L_
+from ...ops.proposal import PyramidProposal
+from ..utils.layers import ConvLayer
+
+HEAD_CPAD = 64   # fused cls+reg output channels padded so that dgrad's reduction dim is a multiple of 64
+
+
+class RPNHead:
+    def __init__(self, channels, strides, arena, ws, device, gen, ratios=(0.5, 1.0, 2.0), scales=(8,),
+                 pre_nms_top_n=2000, post_nms_top_n=2000, nms_thresh=0.7, min_size=0.0, batch_size=256,
+                 fg_fraction=0.5, fg_thresh=0.7, bg_thresh=0.3, sigma=3.0, seed=99):
+        kw = dict(arena=arena, ws=ws, device=device, gen=gen)
+        self.A = len(ratios) * len(scales)
+        assert 5 * self.A <= HEAD_CPAD
+        self.out = ConvLayer("rpn.out", channels, HEAD_CPAD, 1, init_std=0.01, **kw)
+        self.conv = ConvLayer("rpn.conv", channels, channels, 3, init_std=0.01, **kw)
+        self.strides = list(strides)
+        self.base = [torch.from_numpy(A_.generate_base_anchors(s, ratios, scales)).to(device) for s in strides]
+        self.proposal = PyramidProposal(self.base, strides, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size)
+        self.batch_size, self.fg_fraction, self.fg_thresh, self.bg_thresh = batch_size, fg_fraction, fg_thresh, bg_thresh
+        self.sigma, self.seed, self.device, self.C = sigma, seed, device, channels
+        self.bufs = {}
+        self.anchors = None
+        self.level_shapes = None
+
+    def layers(self):
+        return [self.out, self.conv]
+
+    def _buf(self, key, shape, dtype=torch.bfloat16, zero=False):
+        b = self.bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = b
+        return b
+
+    def plan(self, p_shapes, g_max):
+        for s in p_shapes:
+            self.conv.plan(s)
+            self.out.plan(s)
+        self.level_shapes = [(s[1], s[2]) for s in p_shapes]
+        N = p_shapes[0][0]
+        self.anchors = torch.cat([A_.generate_anchors(self.base[l], H, W, self.strides[l])
+                                  for l, (H, W) in enumerate(self.level_shapes)])
+        self.level_offsets = [0]
+        for (H, W) in self.level_shapes:
+            self.level_offsets.append(self.level_offsets[-1] + H * W * self.A)
+        At = self.anchors.shape[0]
+        self.at_ws = A_.AnchorTargetWorkspace(N, At, g_max, self.device)
+        self.at_out = (torch.empty((N, At), dtype=torch.int32, device=self.device),
+                       torch.empty((N, At), dtype=torch.int32, device=self.device),
+                       torch.empty((N, At, 4), dtype=torch.float32, device=self.device),
+                       torch.empty((N, At), dtype=torch.float32, device=self.device))
+        self.nparts = [L_.rpn_loss_num_partials(N, H, W) for (H, W) in self.level_shapes]
+        self.partial = torch.zeros((2 * sum(self.nparts),), dtype=torch.float32, device=self.device)
+        self.loss = torch.zeros((2,), dtype=torch.float32, device=self.device)
+
+    def forward(self, P):
+        self.P = P
+        self.t, self.h = [], []
+        for l, p in enumerate(P):
+            t = self.conv.forward(p, relu=True, out=self._buf("t%d" % l, p.shape))
+            h = self.out.forward(t, out=self._buf("h%d" % l, p.shape[:3] + (HEAD_CPAD,)))
+            self.t.append(t)
+            self.h.append(h)
+        return self.h
+
+    def get_proposals(self, im_info):
+        return self.proposal(self.h, self.h, im_info, layout="nhwc_fused")
+
+    def loss_and_grad(self, gt_boxes, im_info, step, image_offset, loss_scale=1.0):
+        """Assign anchors, compute the RPN losses and d(loss)/d(head) for every level (bf16)."""
+        labels, _, targets, _ = A_.assign_anchor(self.anchors, gt_boxes, im_info, self.fg_thresh, self.bg_thresh, 0.0,
+                                                 self.batch_size, self.fg_fraction, self.seed, step, image_offset,
+                                                 self.at_ws, self.at_out)
+        N = gt_boxes.shape[0]
+        norm = 1.0 / float(N * self.batch_size)
+        self.gh = []
+        off = 0
+        for l, h in enumerate(self.h):
+            g = self._buf("gh%d" % l, h.shape)
+            L_.rpn_loss_level(h, self.A, labels, targets, self.level_offsets[l], self.sigma, norm, loss_scale, g,
+                              self.partial[2 * off:])
+            off += self.nparts[l]
+            self.gh.append(g)
+        L_.loss_finalize(self.partial, off, 2, self.loss)
+        return self.loss
+
+    def backward(self, dP, dP_has_grad):
+        """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False)."""
+        for l in range(len(self.h)):
+            acc = l > 0
+            self.out.backward_weight(self.t[l], self.gh[l], accumulate=acc)
+            d_t = self.out.backward_data(self.gh[l], self.t[l].shape, relu_mask=self.t[l],
+                                         out=self._buf("dt%d" % l, self.t[l].shape))
+            self.conv.backward_weight(self.P[l], d_t, accumulate=acc)
+            self.conv.backward_data(d_t, self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])

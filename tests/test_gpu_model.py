@@ -1,0 +1,59 @@
+"""End-to-end GPU tests of the assembled Faster R-CNN R50-FPN training step (small image)."""
+import numpy as np
+import pytest
+
+from conftest import synth_gt
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(N, H, W, seed=0):
+    import torch
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(1234 + seed)
+    image = torch.randn((N, 3, H, W), generator=g).cuda()
+    gt = torch.from_numpy(synth_gt(rng, N, 16, H, W - 5)).cuda()
+    im_info = torch.tensor([[H, W - 5, 1.0]] * N, dtype=torch.float32).cuda()
+    return image, gt, im_info
+
+
+def test_train_step_runs_and_is_deterministic(hip):
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    N, H, W = 2, 256, 320
+    image, gt, im_info = _inputs(N, H, W)
+    losses = []
+    grads = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+        rpn, rcnn = m.forward_backward(image, gt, im_info, step=3, image_offset=0)
+        torch.cuda.synchronize()
+        losses.append(torch.cat([rpn, rcnn]).cpu().numpy())
+        grads.append(m.arena.g.clone())
+    assert np.all(np.isfinite(losses[0])) and np.all(losses[0] > 0), losses[0]
+    # rpn cls loss of an untrained head is ~ln 2 per sampled anchor
+    assert 0.3 < losses[0][0] < 1.5, losses[0]
+    assert 2.0 < losses[0][2] < 7.0, losses[0]      # ~ln(81) = 4.39
+    assert np.array_equal(losses[0], losses[1])
+    g0, g1 = grads
+    assert torch.isfinite(g0).all()
+    # everything except the RoIAlign-atomics-dependent part is bit-reproducible; with fp32 atomics the
+    # pyramid gradient differs in the last bits, so compare with a tight tolerance instead
+    denom = g0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 1e-3 * denom
+    assert g0.abs().sum().item() > 0
+
+
+def test_loss_decreases_on_a_fixed_batch(hip):
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    N, H, W = 2, 256, 320
+    image, gt, im_info = _inputs(N, H, W, seed=1)
+    m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+    hist = []
+    for it in range(12):
+        rpn, rcnn = m.train_step(image, gt, im_info, step=0, image_offset=0, lr=0.01)
+        hist.append(float((rpn.sum() + rcnn.sum()).item()))
+    assert np.all(np.isfinite(hist)), hist
+    assert hist[-1] < 0.8 * hist[0], hist
