@@ -17,7 +17,9 @@ class Bottleneck:
         kw = dict(arena=arena, ws=ws, device=device, gen=gen, trainable=trainable, train_bias=False)
         self.trainable, self.need_dx = trainable, need_dx
         # registered in backward completion order: conv3, conv2, conv1 / downsample
-        self.conv3 = ConvLayer(name + ".conv3", planes, planes * 4, 1, **kw)
+        # random-init stand-in for pretrained weights: the residual branch's last conv starts small so that
+        # activations stay O(1) through 16 blocks without live BatchNorm statistics (frozen BN is identity here)
+        self.conv3 = ConvLayer(name + ".conv3", planes, planes * 4, 1, init_std=0.25 * (2.0 / planes) ** 0.5, **kw)
         self.conv2 = ConvLayer(name + ".conv2", planes, planes, 3, stride, **kw)
         self.conv1 = ConvLayer(name + ".conv1", cin, planes, 1, **kw)
         self.down = ConvLayer(name + ".down", cin, planes * 4, 1, stride, 0, **kw) if downsample else None
