@@ -34,7 +34,7 @@ def test_train_step_runs_and_is_deterministic(hip):
     assert np.all(np.isfinite(losses[0])) and np.all(losses[0] > 0), losses[0]
     # rpn cls loss of an untrained head is ~ln 2 per sampled anchor
     assert 0.3 < losses[0][0] < 1.5, losses[0]
-    assert 2.0 < losses[0][2] < 7.0, losses[0]      # ~ln(81) = 4.39
+    assert 2.0 < losses[0][2] < 12.0, losses[0]     # ~ln(81) = 4.39 plus the spread of an untrained head
     assert np.array_equal(losses[0], losses[1])
     g0, g1 = grads
     assert torch.isfinite(g0).all()
