@@ -50,6 +50,20 @@ class FasterRCNN:
         self.dist = None
         self.pending = []
 
+    def export_params(self):
+        """name -> fp32 CPU tensor of every parameter as the kernels see it (bf16 filters, fp32 biases)."""
+        out = {"stem.weight": self.backbone.stem_w.float().cpu(), "stem.bias": self.backbone.stem_b.float().cpu()}
+        frozen = [l for st in self.backbone.stages for b in st for l in b.layers() if not l.trainable]
+        for l in self.layers + frozen:
+            out[l.name + ".weight"] = l.w_bf16.float().cpu()
+            if l.has_bias:
+                out[l.name + ".bias"] = l.bias_f32.float().cpu()
+        return out
+
+    def export_grads(self):
+        """name -> fp32 CPU gradient of every trainable parameter."""
+        return {e[0]: self.arena.view(i, "g").float().cpu() for i, e in enumerate(self.arena.entries)}
+
     def num_params(self):
         return sum(e[3] for e in self.arena.entries)
 
