@@ -12,6 +12,7 @@ from .bbox_heads import BBoxHead
 from .necks import FPN
 from .roi_extractors import FPNRoIExtractor
 from .rpn_heads import RPNHead
+from .utils.dp import BucketReducer
 from .utils.layers import ParamArena, Workspace
 
 
@@ -48,7 +49,8 @@ class FasterRCNN:
             self.stage_marks[si] = e[2] + (e[3] + 63) // 64 * 64
         self.planned = None
         self.dist = None
-        self.pending = []
+        self.world = 1
+        self.reducer = BucketReducer(self.arena.g, None)
 
     def export_params(self):
         """name -> fp32 CPU tensor of every parameter as the kernels see it (bf16 filters, fp32 biases)."""
@@ -75,6 +77,7 @@ class FasterRCNN:
         import torch.distributed as dist
         self.dist = dist
         self.world = world_size
+        self.reducer = BucketReducer(self.arena.g, dist)
 
     def plan(self, N, H, W, g_max):
         key = (N, H, W, g_max)
@@ -94,8 +97,7 @@ class FasterRCNN:
 
     # ---- gradient buckets -----------------------------------------------------------------------
     def _reduce(self, lo, hi):
-        if self.dist is not None and hi > lo:
-            self.pending.append(self.dist.all_reduce(self.arena.g[lo:hi], async_op=True))
+        self.reducer.reduce(lo, hi)
 
     def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0):
         """image NCHW [N,3,H,W]; gt_boxes [N,G,5] f32 (class < 0 padding); im_info [N,3] f32."""
@@ -138,10 +140,8 @@ class FasterRCNN:
                 b.backward(ds, None, False)
 
     def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
-        for w in self.pending:
-            w.wait()
-        self.pending = []
-        rescale = 1.0 / self.world if self.dist is not None else 1.0
+        self.reducer.wait()
+        rescale = 1.0 / self.world
         self.arena.sgd_step(lr, momentum, wd, rescale)
         self.refresh_transposed()
 

@@ -317,3 +317,38 @@ def test_errors_are_reported_not_thrown(hip):
     boxes = torch.zeros((1, 5000, 4), device="cuda")
     with pytest.raises(MxdetError, match="n_max"):
         nms_batched(boxes, torch.tensor([5000], dtype=torch.int32, device="cuda"), 0.5)
+
+
+def test_against_committed_golden_vectors(hip):
+    """HIP ops reproduce tests/golden/det_small.npz bit for bit (vectors made by tests/golden/make_golden.py)."""
+    import os
+    import torch
+    from mxdetection_amd.core.anchor import assign_anchor, generate_base_anchors
+    from mxdetection_amd.core.bbox import sample_rois
+    from mxdetection_amd.ops import PyramidProposal, nms_batched, roi_align_forward
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "det_small.npz"))
+    b = G["nms_boxes"]
+    for thr, key in ((0.5, "nms_keep_0p5"), (0.7, "nms_keep_0p7")):
+        keep, num = nms_batched(_t(b[None]), _t(np.array([len(b)], np.int32)), thr)
+        assert np.array_equal(keep.cpu().numpy()[0, : int(num[0])], G[key])
+    strides, shapes, A, N = [8, 16], [(12, 16), (6, 8)], 3, 2
+    base = [generate_base_anchors(s) for s in strides]
+    fused = []
+    for l, (H, W) in enumerate(shapes):
+        f = np.zeros((N, H, W, 16), np.float32)
+        f[..., :A] = G["prop_sc%d" % l].reshape(N, H, W, A)
+        f[..., A:5 * A] = G["prop_dl%d" % l].reshape(N, H, W, 4 * A)
+        fused.append(_t(f, torch.bfloat16))
+    op = PyramidProposal([_t(x) for x in base], strides, 100, 60, 0.7, 2.0)
+    rois, sc, anc, num = op(fused, fused, _t(G["prop_info"]))
+    assert np.array_equal(rois.cpu().numpy(), G["prop_rois"]) and np.array_equal(anc.cpu().numpy(), G["prop_anchor"])
+    assert np.array_equal(num.cpu().numpy(), G["prop_num"]) and np.array_equal(sc.cpu().numpy(), G["prop_scores"])
+    lab, _, tg, mi = assign_anchor(_t(G["at_anchors"]), _t(G["at_gt"]), _t(G["prop_info"]), 0.7, 0.3, 0.0, 64, 0.5, 99, 1, 0)
+    assert np.array_equal(lab.cpu().numpy(), G["at_labels"]) and np.array_equal(tg.cpu().numpy(), G["at_targets"])
+    out = sample_rois(_t(G["pt_rois_in"]), _t(np.array([60, 45], np.int32)), _t(G["at_gt"]), 32, 0.25, 0.5, 0.5, 0.0, 81,
+                      False, (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2), 99, 1, 0)
+    assert np.array_equal(out[0].cpu().numpy(), G["pt_rois"]) and np.array_equal(out[1].cpu().numpy(), G["pt_labels"])
+    assert np.array_equal(out[2].cpu().numpy(), G["pt_targets"])
+    o = roi_align_forward([_bf16_t(G["ra_f0"]), _bf16_t(G["ra_f1"])], [1 / 8, 1 / 16], _t(G["ra_rois"]), _t(G["ra_levels"]),
+                          (7, 7), 2, 3)
+    assert np.array_equal(_bits(o), G["ra_out"])
