@@ -108,12 +108,14 @@ int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* im_info /* 
  * foreground) with Philox keys (mxdet_math.h: mxdet_sample_key, streams 0/1); batch_size <= 0 keeps
  * every label (RetinaNet). Outputs: labels[N,A_total] int32, matched_gt[N,A_total] int32 (argmax GT,
  * lowest index on ties), bbox_targets[N,A_total,4] (encoded for label==1, else 0),
- * max_iou[N,A_total] (may be NULL). */
+ * max_iou[N,A_total] (may be NULL). step_dev (may be NULL): device word that overrides `step` when
+ * the launch is replayed from a hipGraph (kernel arguments are frozen at capture). */
 size_t mxdet_anchor_target_workspace_bytes(int32_t N, int64_t A_total, int32_t G_max);
 int mxdet_anchor_target(const float* anchors, int64_t A_total, const float* gt_boxes, int32_t N,
                         int32_t G_max, const float* im_info, float fg_thresh, float bg_thresh,
                         float allowed_border, int32_t batch_size, float fg_fraction, uint32_t seed,
-                        uint32_t step, uint32_t image_offset, int32_t* labels, int32_t* matched_gt,
+                        uint32_t step, const uint32_t* step_dev, uint32_t image_offset, int32_t* labels,
+                        int32_t* matched_gt,
                         float* bbox_targets, float* max_iou, void* workspace, size_t workspace_bytes,
                         mxdet_stream_t stream);
 
@@ -132,7 +134,7 @@ int mxdet_proposal_target(const float* rois, const int32_t* num_rois, int32_t ro
                           float fg_fraction, float fg_thresh, float bg_hi, float bg_lo,
                           int32_t num_classes, int32_t class_agnostic,
                           const float* means /* HOST [4] */, const float* stds /* HOST [4] */,
-                          uint32_t seed, uint32_t step,
+                          uint32_t seed, uint32_t step, const uint32_t* step_dev,
                           uint32_t image_offset, float* out_rois, int32_t* labels,
                           float* bbox_targets, float* bbox_weights, int32_t* matched_gt,
                           int32_t* num_fg, mxdet_stream_t stream);

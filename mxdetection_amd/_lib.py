@@ -58,9 +58,9 @@ SIGNATURES = {
                                c_vp, c_sz, c_vp]),
     "mxdet_anchor_target_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32]),
     "mxdet_anchor_target": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_f32, c_f32, c_f32, c_i32, c_f32,
-                                    c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                    c_u32, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_proposal_target": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32,
-                                      c_i32, c_i32, P(c_f32), P(c_f32), c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
+                                      c_i32, c_i32, P(c_f32), P(c_f32), c_u32, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp,
                                       c_vp, c_vp, c_vp, c_vp]),
     "mxdet_fpn_level_map": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_roi_align_fwd": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp,

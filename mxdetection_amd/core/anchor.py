@@ -42,7 +42,7 @@ class AnchorTargetWorkspace:
 
 
 def assign_anchor(anchors, gt_boxes, im_info, fg_thresh=0.7, bg_thresh=0.3, allowed_border=0.0, batch_size=256,
-                  fg_fraction=0.5, seed=0, step=0, image_offset=0, workspace=None, out=None):
+                  fg_fraction=0.5, seed=0, step=0, image_offset=0, workspace=None, out=None, step_dev=None):
     """RPN / RetinaNet targets. anchors [A,4], gt_boxes [N,G,5], im_info [N,3].
 
     Returns (labels [N,A] i32, matched_gt [N,A] i32, bbox_targets [N,A,4] f32, max_iou [N,A] f32).
@@ -61,7 +61,7 @@ def assign_anchor(anchors, gt_boxes, im_info, fg_thresh=0.7, bg_thresh=0.3, allo
     else:
         labels, matched, targets, max_iou = out
     check(lib.mxdet_anchor_target(ptr(anchors), A, ptr(gt_boxes), N, G, ptr(im_info), fg_thresh, bg_thresh,
-                                  allowed_border, batch_size, fg_fraction, seed, step, image_offset, ptr(labels),
+                                  allowed_border, batch_size, fg_fraction, seed, step, ptr(step_dev), image_offset, ptr(labels),
                                   ptr(matched), ptr(targets), ptr(max_iou), ptr(workspace.buf), workspace.nbytes,
                                   stream_ptr()), "anchor_target")
     return labels, matched, targets, max_iou

@@ -28,7 +28,7 @@ def bbox_overlaps(boxes, query_boxes):
 
 def sample_rois(rois, num_rois, gt_boxes, rois_per_image=512, fg_fraction=0.25, fg_thresh=0.5, bg_thresh_hi=0.5,
                 bg_thresh_lo=0.0, num_classes=81, class_agnostic=False, bbox_means=(0.0, 0.0, 0.0, 0.0),
-                bbox_stds=(0.1, 0.1, 0.2, 0.2), seed=0, step=0, image_offset=0):
+                bbox_stds=(0.1, 0.1, 0.2, 0.2), seed=0, step=0, image_offset=0, step_dev=None):
     """proposal-target. rois [N,S,5], num_rois [N] int32, gt_boxes [N,G,5] (class < 0 = padding).
 
     Returns (rois [N,R,5], labels [N,R] i32, bbox_targets [N,R,D], bbox_weights [N,R,D], matched_gt [N,R] i32,
@@ -51,6 +51,6 @@ def sample_rois(rois, num_rois, gt_boxes, rois_per_image=512, fg_fraction=0.25, 
     stds = (C.c_float * 4)(*bbox_stds)
     check(lib.mxdet_proposal_target(ptr(rois), ptr(num_rois), S, ptr(gt_boxes), N, G, R, fg_fraction, fg_thresh,
                                     bg_thresh_hi, bg_thresh_lo, num_classes, int(class_agnostic), means, stds,
-                                    seed, step, image_offset, ptr(out_rois), ptr(labels), ptr(tgt), ptr(wgt),
+                                    seed, step, ptr(step_dev), image_offset, ptr(out_rois), ptr(labels), ptr(tgt), ptr(wgt),
                                     ptr(matched), ptr(num_fg), stream_ptr()), "proposal_target")
     return out_rois, labels, tgt, wgt, matched, num_fg

@@ -55,15 +55,16 @@ proposal_topk_kernel(PyramidDev p, int pre_n, int Kpad, unsigned long long* __re
     kv = (~mxdet_float_key(s)) & keymask;
     return true;
   };
-  auto emitf = [&](int i, bool chosen, unsigned kv) {
-    if (chosen) {
+  SelectResult sel = block_select_threshold(nl, pre_n, nbits, keyf, sm);
+  for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+    float sc = pyr_score(p, l, n, i);
+    unsigned fk = mxdet_float_key(sc);
+    if (sel.chosen((~fk) & keymask, (unsigned)i)) {
       int pos = atomicAdd(&n_sel, 1);
-      (void)kv;
-      unsigned fk = mxdet_float_key(pyr_score(p, l, n, i));
       list[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
     }
-  };
-  block_select_smallest(nl, pre_n, nbits, keyf, emitf, sm);
+  }
+  __syncthreads();
   block_bitonic_sort_desc(list, Kpad);
   int cnt = n_sel;
   for (int i = threadIdx.x; i < pre_n; i += blockDim.x) keys[(long long)b * pre_n + i] = list[i];

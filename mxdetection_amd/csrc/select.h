@@ -1,10 +1,13 @@
 // select.h -- workgroup-level "k smallest (key, index)" selection and LDS bitonic sort.
 //
 // One 1024-thread workgroup (16 wave64s) owns one list (an image, or an image x pyramid level).
-// Selection is an 8-bit radix select over 32-bit keys through an LDS histogram (2 or 4 passes),
-// followed by one pass in index order that resolves ties on the threshold key by a block-wide
-// ballot/popcount prefix (so "ties -> lower index first" is exact, which bf16 scores need: many
-// anchors share one bf16 logit). Integer-only, so results are bit-exact against the C oracle.
+// Selection is an 8-bit radix select through an LDS histogram: 2 or 4 passes over the 32-bit keys
+// find the threshold key T; if the elements equal to T are not all taken (ties -- common for bf16
+// logits, where thousands of anchors share one value) 4 more passes over the *index* digits of those
+// elements find the index threshold IT. An element is chosen iff
+//       key < T  ||  (key == T && index <= IT)
+// which is exactly "the k smallest by (key, index)" -- a pure predicate, so the caller applies it in
+// parallel (no ordered compaction pass). Integer-only: bit-exact against the C oracle.
 #pragma once
 #include "common.h"
 
@@ -16,19 +19,29 @@ struct SelectSmem {
   unsigned prefix;
   int remaining;
   int flag_all;
+  int bin_count;
+};
+
+struct SelectResult {
+  unsigned T, IT;
+  int mode;    // 0: predicate above, 1: every candidate chosen, 2: none chosen
+  int n_cand;  // number of candidates seen
+  __device__ __forceinline__ bool chosen(unsigned key, unsigned idx) const {
+    return mode == 1 || (mode == 0 && (key < T || (key == T && idx <= IT)));
+  }
 };
 
 // keyf(i, key&) -> bool : is element i a candidate, and its key (smaller = preferred). Only the top
-// `nbits` (16 or 32) bits of keys may be non-zero.
-// emitf(i, chosen, key) is called exactly once for every candidate, in a pass that walks i in
-// ascending order chunk by chunk.
-template <class KeyF, class EmitF>
-__device__ inline void block_select_smallest(int n, int k, int nbits, KeyF keyf, EmitF emitf,
-                                             SelectSmem& sm) {
+// `nbits` (16 or 32) bits of keys may be non-zero. All threads must call with the same arguments.
+template <class KeyF>
+__device__ inline SelectResult block_select_threshold(int n, int k, int nbits, KeyF keyf, SelectSmem& sm) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  SelectResult res;
+  res.T = 0; res.IT = 0xffffffffu; res.mode = 0; res.n_cand = 0;
   unsigned prefix = 0, mask = 0;
   int remaining = k < 0 ? 0 : k;
-  bool all = false;
+  int eq_count = 0;
+  bool first = true;
   for (int shift = 24; shift >= 32 - nbits; shift -= 8) {
     for (int i = tid; i < 256; i += nt) sm.hist[i] = 0;
     __syncthreads();
@@ -38,47 +51,73 @@ __device__ inline void block_select_smallest(int n, int k, int nbits, KeyF keyf,
     }
     __syncthreads();
     if (tid == 0) {
-      int cum = 0, b = 0;
+      int cum = 0, b = 0, total = 0;
+      if (first)
+        for (int j = 0; j < 256; ++j) total += (int)sm.hist[j];
       for (; b < 256; ++b) {
         int c = (int)sm.hist[b];
-        if (cum + c >= remaining) break;
+        if (cum + c >= remaining && c > 0) break;
         cum += c;
       }
+      if (first) sm.scratch[0] = total;
       if (b == 256) {
-        sm.flag_all = 1;  // fewer candidates than requested: take all
+        sm.flag_all = 1;  // fewer candidates than requested
       } else {
         sm.flag_all = 0;
         sm.prefix = prefix | ((unsigned)b << shift);
         sm.remaining = remaining - cum;
+        sm.bin_count = (int)sm.hist[b];
       }
     }
     __syncthreads();
+    if (first) res.n_cand = sm.scratch[0];
+    first = false;
     if (sm.flag_all) {
-      all = true;
-      break;
+      res.mode = 1;
+      __syncthreads();
+      return res;
     }
     prefix = sm.prefix;
     remaining = sm.remaining;
+    eq_count = sm.bin_count;
     mask |= 255u << shift;
   }
   __syncthreads();
+  if (k <= 0) {
+    res.mode = 2;
+    return res;
+  }
+  res.T = prefix;
+  if (remaining >= eq_count) return res;  // every element equal to T is taken: IT stays at max
+  // ties on T: find the `remaining`-th smallest index among the elements with key == T
   const unsigned T = prefix;
-  const int need_eq = remaining;
-  int eq_base = 0;
-  for (int base = 0; base < n; base += nt) {
-    int i = base + tid;
-    unsigned kv = 0;
-    bool c = (i < n) && keyf(i, kv);
-    bool is_eq = c && !all && kv == T;
-    int tot;
-    int r = block_excl_count(is_eq, sm.scratch, &tot);
-    if (c) {
-      bool chosen = all || kv < T || (is_eq && (eq_base + r) < need_eq);
-      emitf(i, chosen, kv);
+  unsigned ip = 0, im = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += nt) sm.hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+      unsigned kv;
+      if (((unsigned)i & im) == ip && keyf(i, kv) && kv == T) atomicAdd(&sm.hist[((unsigned)i >> shift) & 255u], 1u);
     }
-    eq_base += tot;
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, b = 0;
+      for (; b < 256; ++b) {
+        int c = (int)sm.hist[b];
+        if (cum + c >= remaining && c > 0) break;
+        cum += c;
+      }
+      sm.prefix = ip | ((unsigned)b << shift);
+      sm.remaining = remaining - cum;
+    }
+    __syncthreads();
+    ip = sm.prefix;
+    remaining = sm.remaining;
+    im |= 255u << shift;
   }
   __syncthreads();
+  res.IT = ip;
+  return res;
 }
 
 // Sort P (power of two) 64-bit keys in LDS in DESCENDING order with the whole workgroup.

@@ -53,7 +53,9 @@ anchor_iou_kernel(const float4* __restrict__ anchors, long long A_total, const f
 __global__ void __launch_bounds__(256)
 anchor_label_kernel(const float4* __restrict__ anchors, long long A_total, const float* __restrict__ gt,
                     int G_max, const float* __restrict__ max_iou, const unsigned* __restrict__ gt_max,
-                    float fg_thresh, float bg_thresh, int32_t* __restrict__ labels) {
+                    float fg_thresh, float bg_thresh, unsigned seed, unsigned step,
+                    const unsigned* __restrict__ step_dev, unsigned image_offset,
+                    int32_t* __restrict__ labels, unsigned* __restrict__ keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sg = (float*)smem_raw;
   unsigned* sgm = (unsigned*)(sg + G_max * 5);
@@ -78,14 +80,20 @@ anchor_label_kernel(const float4* __restrict__ anchors, long long A_total, const
     }
   }
   labels[(long long)n * A_total + a] = lab;
+  // sampling key of this anchor in its stream (0 = fg, 1 = bg), computed once, in parallel
+  if (step_dev) step = *step_dev;
+  keys[(long long)n * A_total + a] =
+      lab >= 0 ? mxdet_sample_key(seed, step, image_offset + (unsigned)n, lab == 1 ? 0u : 1u, (unsigned)a) : 0u;
 }
 
 // An inside anchor of an image with no valid GT has max_iou = -1 above; the lineage labels those
 // background. Handled here: stage 2b turns them into label 0 when the image has no GT at all.
 __global__ void __launch_bounds__(256)
 anchor_nogt_kernel(const float4* __restrict__ anchors, long long A_total, const float* __restrict__ gt,
-                   int G_max, const float* __restrict__ im_info, float allowed_border,
-                   int32_t* __restrict__ labels, float* __restrict__ max_iou) {
+                   int G_max, const float* __restrict__ im_info, float allowed_border, unsigned seed,
+                   unsigned step, const unsigned* __restrict__ step_dev, unsigned image_offset,
+                   int32_t* __restrict__ labels, float* __restrict__ max_iou,
+                   unsigned* __restrict__ keys) {
   const int n = blockIdx.y;
   __shared__ int any;
   if (threadIdx.x == 0) any = 0;
@@ -101,60 +109,61 @@ anchor_nogt_kernel(const float4* __restrict__ anchors, long long A_total, const 
   bool inside = (b.x >= -allowed_border) && (b.y >= -allowed_border) &&
                 (b.z < im_w + allowed_border) && (b.w < im_h + allowed_border);
   if (inside) {
+    if (step_dev) step = *step_dev;
     labels[(long long)n * A_total + a] = 0;
     max_iou[(long long)n * A_total + a] = 0.0f;
+    keys[(long long)n * A_total + a] = mxdet_sample_key(seed, step, image_offset + (unsigned)n, 1u, (unsigned)a);
   }
 }
 
-// stage 3: per-image subsampling (one 1024-thread workgroup per image)
+// stage 3: per-image selection thresholds (one 1024-thread workgroup per image). The k smallest
+// (key, index) of each stream are described by a SelectResult; stage 4 applies them in parallel.
+struct AnchorSel { unsigned T[2], IT[2]; int mode[2]; };
+
 __global__ void __launch_bounds__(1024)
-anchor_sample_kernel(long long A_total, int batch_size, int max_fg, unsigned seed, unsigned step,
-                     unsigned image_offset, int32_t* __restrict__ labels) {
+anchor_sample_kernel(long long A_total, int batch_size, int max_fg, const int32_t* __restrict__ labels,
+                     const unsigned* __restrict__ keys, AnchorSel* __restrict__ sel) {
   __shared__ SelectSmem sm;
-  __shared__ int cnt_fg;
   const int n = blockIdx.x;
-  int32_t* lab = labels + (long long)n * A_total;
-  const unsigned image = image_offset + (unsigned)n;
+  const int32_t* lab = labels + (long long)n * A_total;
+  const unsigned* key = keys + (long long)n * A_total;
   const int A = (int)A_total;
-  if (threadIdx.x == 0) cnt_fg = 0;
-  __syncthreads();
-  {
-    auto keyf = [&](int i, unsigned& kv) -> bool {
-      if (lab[i] != 1) return false;
-      kv = mxdet_sample_key(seed, step, image, 0u, (unsigned)i);
-      return true;
-    };
-    auto emitf = [&](int i, bool chosen, unsigned) {
-      if (chosen) atomicAdd(&cnt_fg, 1); else lab[i] = -1;
-    };
-    block_select_smallest(A, max_fg, 32, keyf, emitf, sm);
-  }
-  __syncthreads();
-  int num_bg = batch_size - cnt_fg;
-  {
-    auto keyf = [&](int i, unsigned& kv) -> bool {
-      if (lab[i] != 0) return false;
-      kv = mxdet_sample_key(seed, step, image, 1u, (unsigned)i);
-      return true;
-    };
-    auto emitf = [&](int i, bool chosen, unsigned) {
-      if (!chosen) lab[i] = -1;
-    };
-    block_select_smallest(A, num_bg, 32, keyf, emitf, sm);
+  auto kfg = [&](int i, unsigned& kv) -> bool { kv = key[i]; return lab[i] == 1; };
+  auto kbg = [&](int i, unsigned& kv) -> bool { kv = key[i]; return lab[i] == 0; };
+  SelectResult rf = block_select_threshold(A, max_fg, 32, kfg, sm);
+  int nfg = rf.n_cand < max_fg ? rf.n_cand : max_fg;
+  SelectResult rb = block_select_threshold(A, batch_size - nfg, 32, kbg, sm);
+  if (threadIdx.x == 0) {
+    AnchorSel o;
+    o.T[0] = rf.T; o.IT[0] = rf.IT; o.mode[0] = rf.mode;
+    o.T[1] = rb.T; o.IT[1] = rb.IT; o.mode[1] = rb.mode;
+    sel[n] = o;
   }
 }
 
-// stage 4: regression targets
+// stage 4: apply the sampling predicate and write the regression targets
 __global__ void __launch_bounds__(256)
 anchor_encode_kernel(const float4* __restrict__ anchors, long long A_total, const float* __restrict__ gt,
-                     int G_max, const int32_t* __restrict__ labels, const int32_t* __restrict__ argmax,
+                     int G_max, int32_t* __restrict__ labels, const int32_t* __restrict__ argmax,
+                     const unsigned* __restrict__ keys, const AnchorSel* __restrict__ sel,
                      float4* __restrict__ targets) {
   const int n = blockIdx.y;
   long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= A_total) return;
   long long idx = (long long)n * A_total + a;
+  int lab = labels[idx];
+  if (sel != nullptr && lab >= 0) {
+    const AnchorSel s = sel[n];
+    const int st = lab == 1 ? 0 : 1;
+    SelectResult r;
+    r.T = s.T[st]; r.IT = s.IT[st]; r.mode = s.mode[st]; r.n_cand = 0;
+    if (!r.chosen(keys[idx], (unsigned)a)) {
+      lab = -1;
+      labels[idx] = -1;
+    }
+  }
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (labels[idx] == 1) {
+  if (lab == 1) {
     int g = argmax[idx];
     float4 b = anchors[a];
     const float* q = gt + ((long long)n * G_max + g) * 5;
@@ -171,7 +180,8 @@ __global__ void __launch_bounds__(1024)
 proposal_target_kernel(const float* __restrict__ rois, const int32_t* __restrict__ num_rois,
                        int rois_stride, const float* __restrict__ gt, int G_max, int R, int max_fg,
                        float fg_thresh, float bg_hi, float bg_lo, int num_classes, int class_agnostic,
-                       float4 means, float4 stds, unsigned seed, unsigned step, unsigned image_offset,
+                       float4 means, float4 stds, unsigned seed, unsigned step,
+                       const unsigned* __restrict__ step_dev, unsigned image_offset,
                        float* __restrict__ out_rois, int32_t* __restrict__ labels,
                        float* __restrict__ bbox_targets, float* __restrict__ bbox_weights,
                        int32_t* __restrict__ matched_gt, int32_t* __restrict__ num_fg_out) {
@@ -184,11 +194,12 @@ proposal_target_kernel(const float* __restrict__ rois, const int32_t* __restrict
   short* cgt = (short*)(vg + G_max);
   signed char* cstate = (signed char*)(cgt + ((ncap + 7) & ~7));
   __shared__ SelectSmem sm;
-  __shared__ int n_valid_gt, cnt_fg, cnt_bg;
+  __shared__ int n_valid_gt, cnt_bg;
   const int n = blockIdx.x;
   const unsigned image = image_offset + (unsigned)n;
+  if (step_dev) step = *step_dev;
   for (int i = threadIdx.x; i < G_max * 5; i += blockDim.x) sg[i] = gt[(long long)n * G_max * 5 + i];
-  if (threadIdx.x == 0) { cnt_fg = 0; cnt_bg = 0; }
+  if (threadIdx.x == 0) cnt_bg = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     int c = 0;
@@ -229,29 +240,23 @@ proposal_target_kernel(const float* __restrict__ rois, const int32_t* __restrict
     cgt[i] = (short)bi;
   }
   __syncthreads();
-  {
-    auto keyf = [&](int i, unsigned& kv) -> bool {
-      if (cstate[i] != 1) return false;
-      kv = mxdet_sample_key(seed, step, image, 2u, (unsigned)i);
-      return true;
-    };
-    auto emitf = [&](int i, bool chosen, unsigned) {
-      if (chosen) { cstate[i] = 3; atomicAdd(&cnt_fg, 1); }
-    };
-    block_select_smallest(nc, max_fg, 32, keyf, emitf, sm);
-  }
-  __syncthreads();
-  const int nfg = cnt_fg;
-  {
-    auto keyf = [&](int i, unsigned& kv) -> bool {
-      if (cstate[i] != 2) return false;
-      kv = mxdet_sample_key(seed, step, image, 3u, (unsigned)i);
-      return true;
-    };
-    auto emitf = [&](int i, bool chosen, unsigned) {
-      if (chosen) { cstate[i] = 4; atomicAdd(&cnt_bg, 1); }
-    };
-    block_select_smallest(nc, R - nfg, 32, keyf, emitf, sm);
+  auto kfg = [&](int i, unsigned& kv) -> bool {
+    kv = mxdet_sample_key(seed, step, image, 2u, (unsigned)i);
+    return cstate[i] == 1;
+  };
+  auto kbg = [&](int i, unsigned& kv) -> bool {
+    kv = mxdet_sample_key(seed, step, image, 3u, (unsigned)i);
+    return cstate[i] == 2;
+  };
+  SelectResult sel_f = block_select_threshold(nc, max_fg, 32, kfg, sm);
+  const int nfg = sel_f.n_cand < max_fg ? sel_f.n_cand : max_fg;
+  SelectResult sel_b = block_select_threshold(nc, R - nfg, 32, kbg, sm);
+  const int want_bg = (R - nfg) > 0 ? (R - nfg) : 0;
+  if (threadIdx.x == 0) cnt_bg = sel_b.n_cand < want_bg ? sel_b.n_cand : want_bg;
+  for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+    unsigned kv;
+    if (cstate[i] == 1) { kfg(i, kv); if (sel_f.chosen(kv, (unsigned)i)) cstate[i] = 3; }
+    else if (cstate[i] == 2) { kbg(i, kv); if (sel_b.chosen(kv, (unsigned)i)) cstate[i] = 4; }
   }
   __syncthreads();
   const int nbg = cnt_bg;
@@ -317,6 +322,8 @@ struct AnchorWs {
   int32_t* argmax;
   unsigned* gt_max;
   float* max_iou;
+  unsigned* keys;
+  AnchorSel* sel;
   size_t total;
 };
 static AnchorWs carve_anchor(void* base, int N, long long A_total, int G_max) {
@@ -327,6 +334,8 @@ static AnchorWs carve_anchor(void* base, int N, long long A_total, int G_max) {
   w.argmax = (int32_t*)(p + take((size_t)N * A_total * 4));
   w.gt_max = (unsigned*)(p + take((size_t)N * G_max * 4));
   w.max_iou = (float*)(p + take((size_t)N * A_total * 4));
+  w.keys = (unsigned*)(p + take((size_t)N * A_total * 4));
+  w.sel = (AnchorSel*)(p + take((size_t)N * sizeof(AnchorSel)));
   w.total = off;
   return w;
 }
@@ -344,7 +353,8 @@ extern "C" int mxdet_anchor_target(const float* anchors, int64_t A_total, const 
                                    int32_t N, int32_t G_max, const float* im_info, float fg_thresh,
                                    float bg_thresh, float allowed_border, int32_t batch_size,
                                    float fg_fraction, uint32_t seed, uint32_t step,
-                                   uint32_t image_offset, int32_t* labels, int32_t* matched_gt,
+                                   const uint32_t* step_dev, uint32_t image_offset, int32_t* labels,
+                                   int32_t* matched_gt,
                                    float* bbox_targets, float* max_iou, void* workspace,
                                    size_t workspace_bytes, mxdet_stream_t stream) {
   clear_error();
@@ -366,17 +376,20 @@ extern "C" int mxdet_anchor_target(const float* anchors, int64_t A_total, const 
                      (long long)A_total, gt_boxes, G_max, im_info, allowed_border, miou, amax,
                      w.gt_max);
   hipLaunchKernelGGL(anchor_label_kernel, grid, dim3(256), lds, s, (const float4*)anchors,
-                     (long long)A_total, gt_boxes, G_max, miou, w.gt_max, fg_thresh, bg_thresh,
-                     labels);
+                     (long long)A_total, gt_boxes, G_max, miou, w.gt_max, fg_thresh, bg_thresh, seed,
+                     step, step_dev, image_offset, labels, w.keys);
   hipLaunchKernelGGL(anchor_nogt_kernel, grid, dim3(256), 0, s, (const float4*)anchors,
-                     (long long)A_total, gt_boxes, G_max, im_info, allowed_border, labels, miou);
+                     (long long)A_total, gt_boxes, G_max, im_info, allowed_border, seed, step, step_dev,
+                     image_offset, labels, miou, w.keys);
   if (batch_size > 0) {
     int max_fg = (int)(fg_fraction * (float)batch_size);
     hipLaunchKernelGGL(anchor_sample_kernel, dim3(N), dim3(1024), 0, s, (long long)A_total,
-                       batch_size, max_fg, seed, step, image_offset, labels);
+                       batch_size, max_fg, (const int32_t*)labels, (const unsigned*)w.keys, w.sel);
   }
   hipLaunchKernelGGL(anchor_encode_kernel, grid, dim3(256), 0, s, (const float4*)anchors,
-                     (long long)A_total, gt_boxes, G_max, labels, amax, (float4*)bbox_targets);
+                     (long long)A_total, gt_boxes, G_max, labels, amax, (const unsigned*)w.keys,
+                     batch_size > 0 ? (const AnchorSel*)w.sel : (const AnchorSel*)nullptr,
+                     (float4*)bbox_targets);
   return check_launch("anchor_target");
 }
 
@@ -385,8 +398,9 @@ extern "C" int mxdet_proposal_target(const float* rois, const int32_t* num_rois,
                                      int32_t rois_per_image, float fg_fraction, float fg_thresh,
                                      float bg_hi, float bg_lo, int32_t num_classes,
                                      int32_t class_agnostic, const float* means, const float* stds,
-                                     uint32_t seed, uint32_t step, uint32_t image_offset,
-                                     float* out_rois, int32_t* labels, float* bbox_targets,
+                                     uint32_t seed, uint32_t step, const uint32_t* step_dev,
+                                     uint32_t image_offset, float* out_rois, int32_t* labels,
+                                     float* bbox_targets,
                                      float* bbox_weights, int32_t* matched_gt, int32_t* num_fg,
                                      mxdet_stream_t stream) {
   clear_error();
@@ -406,7 +420,7 @@ extern "C" int mxdet_proposal_target(const float* rois, const int32_t* num_rois,
   float4 sd = make_float4(stds[0], stds[1], stds[2], stds[3]);
   hipLaunchKernelGGL(proposal_target_kernel, dim3(N), dim3(1024), lds, as_stream(stream), rois,
                      num_rois, rois_stride, gt_boxes, G_max, rois_per_image, max_fg, fg_thresh, bg_hi,
-                     bg_lo, num_classes, class_agnostic, m, sd, seed, step, image_offset, out_rois,
+                     bg_lo, num_classes, class_agnostic, m, sd, seed, step, step_dev, image_offset, out_rois,
                      labels, bbox_targets, bbox_weights, matched_gt, num_fg);
   return check_launch("proposal_target");
 }

@@ -260,7 +260,7 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
   w.ksplit = ceil_div(steps, w.steps_per_split);
   size_t params = (size_t)d->Cout * w.taps * d->Cin;
   w.slab_bytes = align_up((size_t)w.ksplit * params * sizeof(float), 256);
-  w.colsum_rows = 2048;
+  w.colsum_rows = 256;
   w.colsum_blocks = (int)ceil_div<long long>(M, w.colsum_rows);
   w.colsum_off = w.slab_bytes;
   w.colsum_bytes = align_up((size_t)w.colsum_blocks * d->Cout * sizeof(float), 256);

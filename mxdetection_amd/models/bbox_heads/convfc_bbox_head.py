@@ -45,10 +45,10 @@ class BBoxHead:
         self.loss = torch.zeros((2,), dtype=torch.float32, device=self.device)
         self.loss_ws = L_.loss_workspace(R, self.device)
 
-    def sample(self, rois, num_rois, gt_boxes, step, image_offset):
+    def sample(self, rois, num_rois, gt_boxes, step, image_offset, step_dev=None):
         """proposal-target: returns rois [N*R,5] and keeps labels / targets / weights for the loss."""
         out = B_.sample_rois(rois, num_rois, gt_boxes, self.R, self.fg_fraction, self.fg_thresh, self.bg_hi, self.bg_lo,
-                             self.nc, False, (0.0, 0.0, 0.0, 0.0), self.stds, self.seed, step, image_offset)
+                             self.nc, False, (0.0, 0.0, 0.0, 0.0), self.stds, self.seed, step, image_offset, step_dev)
         self.rois, self.labels, self.tgt, self.wgt, self.matched, self.num_fg = out
         return self.rois.view(-1, 5)
 

@@ -51,6 +51,9 @@ class FasterRCNN:
         self.dist = None
         self.world = 1
         self.reducer = BucketReducer(self.arena.g, None)
+        self.segments = None
+        self._cap = False
+        self._cur_graph = None
 
     def export_params(self):
         """name -> fp32 CPU tensor of every parameter as the kernels see it (bf16 filters, fp32 biases)."""
@@ -97,9 +100,67 @@ class FasterRCNN:
 
     # ---- gradient buckets -----------------------------------------------------------------------
     def _reduce(self, lo, hi):
+        if self._cap:
+            if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
+                self._seg_end()
+                self.segments.append(("reduce", lo, hi))
+                self._seg_begin()
+            return
         self.reducer.reduce(lo, hi)
 
-    def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0):
+    # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
+    def _seg_begin(self):
+        self._cur_graph = torch.cuda.CUDAGraph()
+        self._cur_graph.capture_begin(pool=self._pool)
+
+    def _seg_end(self):
+        self._cur_graph.capture_end()
+        self.segments.append(self._cur_graph)
+        self._cur_graph = None
+
+    def capture(self, image, gt_boxes, im_info, lr, image_offset=0, warmup=2):
+        """Capture forward+backward+update into hipGraph segments (cut only at gradient all-reduces).
+        The RNG step counter is read from device memory (step_dev), inputs from static buffers."""
+        dev = self.device
+        self.static_in = (image.clone(), gt_boxes.clone(), im_info.clone())
+        self.step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        for i in range(warmup):     # eager warm-up: plans shapes and allocates every buffer
+            self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr)
+        torch.cuda.synchronize()
+        self._pool = torch.cuda.graph_pool_handle()
+        self.segments = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._cap = True
+            self._seg_begin()
+            losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev)
+            self.optimizer_step(lr)
+            self._seg_end()
+            self._cap = False
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.static_losses = losses
+
+    def replay(self, image, gt_boxes, im_info, step):
+        """One training step from the captured graphs."""
+        si = self.static_in
+        if image is not si[0]:
+            si[0].copy_(image, non_blocking=True)
+            si[1].copy_(gt_boxes, non_blocking=True)
+            si[2].copy_(im_info, non_blocking=True)
+        self.step_dev.fill_(step)
+        for seg in self.segments:
+            if isinstance(seg, tuple):
+                if seg[0] == "reduce":
+                    self.reducer.reduce(seg[1], seg[2])
+                else:
+                    self.reducer.wait()
+            else:
+                seg.replay()
+        return self.static_losses
+
+    def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0, step_dev=None):
         """image NCHW [N,3,H,W]; gt_boxes [N,G,5] f32 (class < 0 padding); im_info [N,3] f32."""
         N, _, H, W = image.shape
         self.plan(N, H, W, gt_boxes.shape[1])
@@ -107,8 +168,8 @@ class FasterRCNN:
         P = self.neck.forward(C)
         self.rpn_head.forward(P)
         rois, _, _, num_rois = self.rpn_head.get_proposals(im_info)
-        rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset)
-        rois_s = self.bbox_head.sample(rois, num_rois, gt_boxes, step, image_offset)
+        rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset, step_dev=step_dev)
+        rois_s = self.bbox_head.sample(rois, num_rois, gt_boxes, step, image_offset, step_dev)
         pooled = self.roi_extractor.forward(P, rois_s)
         self.bbox_head.forward(pooled)
         rcnn_loss = self.bbox_head.loss_and_grad()
@@ -140,7 +201,13 @@ class FasterRCNN:
                 b.backward(ds, None, False)
 
     def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
-        self.reducer.wait()
+        if self._cap:
+            if self.dist is not None:
+                self._seg_end()
+                self.segments.append(("wait",))
+                self._seg_begin()
+        else:
+            self.reducer.wait()
         rescale = 1.0 / self.world
         self.arena.sgd_step(lr, momentum, wd, rescale)
         self.refresh_transposed()

@@ -77,11 +77,11 @@ class RPNHead:
     def get_proposals(self, im_info):
         return self.proposal(self.h, self.h, im_info, layout="nhwc_fused")
 
-    def loss_and_grad(self, gt_boxes, im_info, step, image_offset, loss_scale=1.0):
+    def loss_and_grad(self, gt_boxes, im_info, step, image_offset, loss_scale=1.0, step_dev=None):
         """Assign anchors, compute the RPN losses and d(loss)/d(head) for every level (bf16)."""
         labels, _, targets, _ = A_.assign_anchor(self.anchors, gt_boxes, im_info, self.fg_thresh, self.bg_thresh, 0.0,
                                                  self.batch_size, self.fg_fraction, self.seed, step, image_offset,
-                                                 self.at_ws, self.at_out)
+                                                 self.at_ws, self.at_out, step_dev)
         N = gt_boxes.shape[0]
         norm = 1.0 / float(N * self.batch_size)
         self.gh = []
