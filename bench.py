@@ -154,7 +154,8 @@ def main():
         dist.broadcast(model.arena.w, 0)
         model.arena.refresh_bf16()
         model.refresh_transposed()
-    lr = 0.02 * (BATCH_PER_GPU * world) / 16.0
+    # linear-scaling rule from lr 0.02 @ batch 16, at the warm-up start factor 1/3 (random-init weights, no BN)
+    lr = 0.02 * (BATCH_PER_GPU * world) / 16.0 / 3.0
     batches = [synth_batch(rank, s, device) for s in range(4)]
 
     use_graph = not args.no_graph

@@ -15,8 +15,11 @@ class FPN:
         kw = dict(arena=arena, ws=ws, device=device, gen=gen)
         L = len(in_channels)
         # registered in backward completion order: output convs fine -> coarse, then laterals
-        self.outs = [ConvLayer("fpn.out%d" % (i + 2), out_channels, out_channels, 3, **kw) for i in range(L)]
-        self.lats = [ConvLayer("fpn.lat%d" % (i + 2), in_channels[i], out_channels, 1, **kw) for i in range(L)]
+        # Xavier-style init (no ReLU follows these convs, so He-normal would double the variance per layer)
+        self.outs = [ConvLayer("fpn.out%d" % (i + 2), out_channels, out_channels, 3,
+                               init_std=(1.0 / (9 * out_channels)) ** 0.5, **kw) for i in range(L)]
+        self.lats = [ConvLayer("fpn.lat%d" % (i + 2), in_channels[i], out_channels, 1,
+                               init_std=(1.0 / in_channels[i]) ** 0.5, **kw) for i in range(L)]
         self.L, self.C, self.extra_p6 = L, out_channels, extra_p6
         self.device = device
         self.bufs = {}

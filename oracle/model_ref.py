@@ -50,8 +50,8 @@ def random_params(depth=50, seed=7, num_classes=81, head_cpad=64):
             if bi == 0:
                 conv(n + ".down", cin, planes * 4, 1)
     for i, c in enumerate([256, 512, 1024, 2048]):
-        conv("fpn.lat%d" % (i + 2), c, 256, 1)
-        conv("fpn.out%d" % (i + 2), 256, 256, 3)
+        conv("fpn.lat%d" % (i + 2), c, 256, 1, std=math.sqrt(1.0 / c))
+        conv("fpn.out%d" % (i + 2), 256, 256, 3, std=math.sqrt(1.0 / (9 * 256)))
     conv("rpn.conv", 256, 256, 3, std=0.01)
     conv("rpn.out", 256, head_cpad, 1, std=0.01)
     ld = (num_classes * 5 + 63) // 64 * 64

@@ -1,10 +1,6 @@
 #!/usr/bin/env python
-"""Per-layer-shape timing of the conv families inside the real training step (HIP events around every launch).
-
-  python tools/conv_report.py [--steps 3]      (GPU box)
-Prints one line per (family, shape): launches/step, avg us, TFLOP/s, share of the step's conv time.
-"""
-import argparse
+"""Per-layer-shape timing of the conv families of the real training step, GPU-saturated (each logged launch is
+re-issued REPS times back to back between HIP events).   python tools/conv_report.py   (GPU box)"""
 import os
 import sys
 
@@ -13,67 +9,51 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=3)
-    args = ap.parse_args()
     import torch
     import bench
     from mxdetection_amd.models import FasterRCNN
-    from mxdetection_amd.ops import dense
-    recs = []
-    on = [False]
-
-    def wrap(fn, family, key_of):
-        def inner(*a, **kw):
-            if not on[0]:
-                return fn(*a, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = fn(*a, **kw)
-            e.record()
-            recs.append((family, key_of(*a, **kw), s, e))
-            return out
-        return inner
-
-    def k_fwd(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None):
-        N, H, W, Cin = x.shape
-        Cout, KH, KW, _ = w.shape
-        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-        return (N * Ho * Wo, Cout, KH * KW * Cin, KH, stride)
-
-    def k_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None):
-        N, Ho, Wo, Cout = dy.shape
-        return (x_shape[0] * x_shape[1] * x_shape[2], x_shape[3], KH * KW * Cout, KH, stride)
-
-    def k_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=False, workspace=None):
-        N, Ho, Wo, Cout = dy.shape
-        return (Cout, KH * KW * x.shape[3], N * Ho * Wo, KH, stride)
-
-    dense.conv2d_forward = wrap(dense.conv2d_forward, "fwd", k_fwd)
-    dense.conv2d_dgrad = wrap(dense.conv2d_dgrad, "dgrad", k_dgrad)
-    dense.conv2d_wgrad = wrap(dense.conv2d_wgrad, "wgrad", k_wgrad)
+    timer = bench.ConvTimer()
+    timer.install()
     m = FasterRCNN("cuda", seed=7)
     batch = bench.synth_batch(0, 0, "cuda")
     for i in range(2):
-        m.train_step(*batch, step=i)
-    torch.cuda.synchronize()
-    on[0] = True
-    for i in range(args.steps):
-        m.train_step(*batch, step=2 + i)
+        m.train_step(*batch, step=i, lr=1e-4)
+    timer.logging = True
+    m.forward_backward(*batch, step=5)
+    timer.logging = False
     torch.cuda.synchronize()
     agg = {}
-    for fam, key, s, e in recs:
-        a = agg.setdefault((fam, key), [0.0, 0])
-        a[0] += s.elapsed_time(e) * 1e-3
-        a[1] += 1
+    REPS = 5
+    for family, flops, fn, a, kw in timer.log:
+        fn(*a, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(REPS):
+            fn(*a, **kw)
+        e.record()
+        e.synchronize()
+        t = s.elapsed_time(e) * 1e-3 / REPS
+        if family == "conv_igemm_fwd":
+            x, w = a[0], a[1]
+            stride = kw.get("stride", a[4] if len(a) > 4 else 1)
+            key = (x.shape[0] * ((x.shape[1] - 1) // stride + 1) * ((x.shape[2] - 1) // stride + 1), w.shape[0],
+                   w.shape[1] * w.shape[2] * w.shape[3], w.shape[1], stride)
+        elif family == "conv_igemm_dgrad":
+            dy, wt, xs = a[0], a[1], a[2]
+            key = (xs[0] * xs[1] * xs[2], xs[3], wt.shape[1] * wt.shape[2] * wt.shape[3], wt.shape[1], a[5] if len(a) > 5 else kw.get("stride", 1))
+        else:
+            x, dy = a[0], a[1]
+            key = (dy.shape[3], a[2] * a[3] * x.shape[3], dy.shape[0] * dy.shape[1] * dy.shape[2], a[2], a[4] if len(a) > 4 else kw.get("stride", 1))
+        r = agg.setdefault((family[5:], key), [0.0, 0, 0.0])
+        r[0] += t
+        r[1] += 1
+        r[2] += flops
     tot = sum(v[0] for v in agg.values())
-    print("%-6s %9s %6s %7s k s  %5s %9s %8s %6s" % ("family", "M", "N", "K", "n/st", "avg_us", "TFLOP/s", "share"))
-    for (fam, key), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print("%-11s %8s %6s %7s k s  %4s %9s %8s %6s" % ("family", "M", "N", "K", "n", "avg_us", "TFLOP/s", "share"))
+    for (fam, key), (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         M, Nn, K, k, s = key
-        fl = 2.0 * M * Nn * K * n
-        print("%-6s %9d %6d %7d %d %d  %5.1f %9.1f %8.1f %5.1f%%" % (fam, M, Nn, K, k, s, n / args.steps, 1e6 * t / n,
-                                                                   fl / t / 1e12, 100 * t / tot))
-    print("conv total per step: %.3f ms" % (1e3 * tot / args.steps))
+        print("%-11s %8d %6d %7d %d %d  %4d %9.1f %8.1f %5.1f%%" % (fam, M, Nn, K, k, s, n, 1e6 * t / n, fl / t / 1e12, 100 * t / tot))
+    print("conv total per step: %.3f ms" % (1e3 * tot))
 
 
 if __name__ == "__main__":
