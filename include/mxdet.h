@@ -245,6 +245,9 @@ int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy, const uin
 size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d);
 int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* dy, float* dw,
                        float* db, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+/* tuning / test hook: force the conv tile configuration on this thread (0 = built-in heuristic,
+ * 1..8 = a specific tile/ring configuration, see conv.hip launch()) */
+int mxdet_debug_force_conv_cfg(int32_t cfg);
 /* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);

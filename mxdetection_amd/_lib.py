@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmxdet_hip.so")
+LIB_PATH = os.environ.get("MXDET_LIB") or os.path.join(_HERE, "libmxdet_hip.so")   # MXDET_LIB: ablation builds
 
 c_i32, c_i64, c_u32, c_f32, c_sz, c_vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_size_t, C.c_void_p
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_conv2d_wgrad_workspace_bytes": (c_sz, [P(ConvDescT)]),
     "mxdet_conv2d_wgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_stem_conv7x7": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_maxpool3x3s2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -9,11 +9,11 @@
 //   reduction  k = (kh, kw, c) with c contiguous        (fwd: c = Cin;      dgrad: c = Cout)
 //
 // Activations are channels-last, so an A-row's 64-channel K-slice is one 128-B line and the MFMA
-// fragment (8 consecutive k per lane) is one ds_read_b128. Tiles: BM x BN x 64 per step, 4 waves,
-// v_mfma_f32_16x16x32_bf16, fp32 accumulators. LDS tiles are [row][64] bf16 with the 16-B chunk index
-// XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128 / ds_write_b128).
-// Global->LDS is register staged and double buffered: the loads of step t+1 are issued before the
-// MFMAs of step t and written to the other buffer after them (one barrier per step).
+// fragment (8 consecutive k per lane) is one ds_read_b128. Tiles: BM x BN x 64 per stage, 4 or 8 waves
+// of 64x64 (or 32x64) accumulator tiles, v_mfma_f32_16x16x32_bf16, fp32 accumulators. LDS tiles are
+// [row][64] bf16 with the 16-B chunk index XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128, see
+// DESIGN.md section 5). Global->LDS is an NS-deep ring of LDS-DMA loads (global_load_lds_dwordx4) with a
+// counted s_waitcnt vmcnt and one raw s_barrier per K-step, so 2-3 stages are always in flight.
 // Epilogue: accumulators -> LDS (fp32) -> rows of 8 channels per lane: + bias, + residual
 // (optionally nearest-upsampled: FPN top-down), ReLU / ReLU-mask, bf16 pack, 16-B coalesced stores.
 #include "common.h"
@@ -36,30 +36,45 @@ struct ConvP {
   int relu, res_up;
   int M;
   int tiles_m, tiles_n;
+  int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <int BM, int BN, int WM, int WN, bool DGRAD>
-__global__ void __launch_bounds__(256)
+// 16 bytes of zeros that padding / out-of-range lanes of an LDS-DMA load read instead of the tensor
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Tile BM x BN x 64 per stage, WM x WN waves each owning a (BM/WM) x (BN/WN) accumulator tile.
+// Global -> LDS goes through an NS-deep ring filled by global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave
+// instruction = 8 tile rows): the loads of stage t+NS-1 are issued while stage t is being multiplied, so
+// NS-1 stages (48-96 KiB per CU) are in flight and the global-load latency is off the critical path.
+// One counted s_waitcnt vmcnt + one raw s_barrier per K-step; the LDS image is lane-linear, so the
+// conflict-avoiding XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read side.
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
+__global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
+  constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
-  constexpr int AI = BM / 32;                       // A chunks per thread
-  constexpr int BI = (BN >= 32) ? BN / 32 : 1;      // B chunks per thread
-  constexpr int STAGE = (BM + BN) * 64;             // elements per buffer
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
+  constexpr int STAGE = (BM + BN) * 64;               // bf16 elements per stage
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "rows must split evenly over the waves");
   static_assert(MT % 2 == 0, "epilogue stages two m-tiles at a time");
+  static_assert(NS >= 2 && (NS - 2) * (GA + GB) <= 63, "vmcnt is a 6-bit counter");
   constexpr int EP_STRIDE = WTN + 4;
-  constexpr int EP_BYTES = 4 * 32 * EP_STRIDE * 4;
-  constexpr int MAIN_BYTES = 2 * STAGE * 2;
+  constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
+  constexpr int MAIN_BYTES = NS * STAGE * 2;
   constexpr int SMEM_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
   uint16_t* smem = (uint16_t*)smem_raw;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
 
   // XCD-aware tile order: blocks that share an XCD (bid % 8) walk consecutive tiles, and consecutive
@@ -73,73 +88,99 @@ conv_igemm_kernel(ConvP p) {
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- per-thread gather geometry ------------------------------------------------------------
-  const int chunk = tid & 7;
-  const int r0 = tid >> 3;
-  int a_h[AI], a_w[AI], a_base[AI];
+  // ---- per-lane gather geometry: lane l of DMA instruction j fills row 8j + (l>>3), 16-B slot l&7 -------
+  // The address math is hoisted out of the K loop (the loop was VALU-issue bound on it): per row a base
+  // element offset and a bitmask of the taps that fall inside the image are computed once; inside the loop
+  // a load costs one add + one bit test + one select, the per-tap displacement being a uniform SALU value.
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const unsigned short* zero = (const unsigned short*)g_zero_page;
+  const int ntaps = p.KH * p.KW;
+  int a_off[GA];
+  unsigned a_mask[GA];
 #pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    int m = m0 + r0 + 32 * i;
+  for (int i = 0; i < GA; ++i) {
+    int ra = (wid * GA + i) * 8 + lrow;
+    int m = m0 + ra;
+    int coff = (lslot ^ ((ra >> 1) & 7)) << 3;
+    unsigned mask = 0;
+    int off = 0;
     if (m < p.M) {
       int img = m / (p.Hd * p.Wd);
       int rem = m - img * (p.Hd * p.Wd);
       int hd = rem / p.Wd, wd = rem - hd * p.Wd;
-      if (DGRAD) { a_h[i] = hd + p.pad; a_w[i] = wd + p.pad; }
-      else { a_h[i] = hd * p.stride - p.pad; a_w[i] = wd * p.stride - p.pad; }
-      a_base[i] = img * (p.Hs * p.Ws);
-    } else {
-      a_h[i] = -1000000; a_w[i] = -1000000; a_base[i] = 0;
+      int h0, w0;   // source position of tap (0,0)
+      if (DGRAD) { h0 = (hd + p.pad) / p.stride; w0 = (wd + p.pad) / p.stride; }
+      else { h0 = hd * p.stride - p.pad; w0 = wd * p.stride - p.pad; }
+      off = ((img * p.Hs + h0) * p.Ws + w0) * p.C + coff;
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw) {
+          bool ok;
+          if (DGRAD) {
+            int th = hd + p.pad - kh, tw = wd + p.pad - kw;
+            int hs = th / p.stride, ws = tw / p.stride;
+            ok = th >= 0 && tw >= 0 && th == hs * p.stride && tw == ws * p.stride && hs < p.Hs && ws < p.Ws;
+          } else {
+            int hs = h0 + kh, ws = w0 + kw;
+            ok = hs >= 0 && ws >= 0 && hs < p.Hs && ws < p.Ws;
+          }
+          if (ok) mask |= 1u << (kh * p.KW + kw);
+        }
     }
+    a_off[i] = off;
+    a_mask[i] = mask;
   }
-  const int Ktot = p.KH * p.KW * p.C;
-  const int cpt = p.C >> 6;            // 64-channel slices per tap
-  const int KT = p.KH * p.KW * cpt;
-  const uint16_t* wrow[BI];
-  bool wvalid[BI];
+  const int Ktot = ntaps * p.C;
+  const int KT = Ktot >> 6;
+  const uint16_t* wrow[GB];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    int n = n0 + r0 + 32 * i;
-    wvalid[i] = (n < p.Ncols) && (r0 + 32 * i < BN);
-    wrow[i] = p.w + (size_t)(wvalid[i] ? n : 0) * Ktot + chunk * 8;
+  for (int i = 0; i < GB; ++i) {
+    int rb = (wid * GB + i) * 8 + lrow;
+    int n = n0 + rb;
+    n = n < p.Ncols ? n : p.Ncols - 1;   // rows past Ncols read a valid row; their columns are never stored
+    wrow[i] = p.w + (size_t)n * Ktot + ((lslot ^ ((rb >> 1) & 7)) << 3);
   }
 
-  uint4 ga[AI], gb[BI];
-  auto load_tiles = [&](int kt) {
-    int tap = kt / cpt;
-    int c0 = (kt - tap * cpt) << 6;
-    int kh = tap / p.KW, kw = tap - kh * p.KW;
+  // running (channel-slice, tap) position of the NEXT stage to load: uniform scalars, no divisions
+  int ld_kt = 0, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
+  auto issue_stage = [&](int buf) {
+    unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
+    const bool live = ld_kt < KT;
+    const int tap = live ? ld_kh * p.KW + ld_kw : 31;                  // bit 31 is never set in a_mask
+    int delta;                                                         // uniform displacement of this tap
+    if (DGRAD) delta = ld_c0 - ((ld_kh / p.stride) * p.Ws + (ld_kw / p.stride)) * p.C;
+    else delta = ld_c0 + (ld_kh * p.Ws + ld_kw) * p.C;
+    const int koff = live ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;  // column of (tap, slice) in the filter rows
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int hs, ws;
-      bool ok;
-      if (DGRAD) {
-        int th = a_h[i] - kh, tw = a_w[i] - kw;
-        if (p.stride == 1) { hs = th; ws = tw; ok = true; }
-        else { hs = th / p.stride; ws = tw / p.stride; ok = (th == hs * p.stride) && (tw == ws * p.stride); }
-        ok = ok && th >= 0 && tw >= 0 && hs < p.Hs && ws < p.Ws;
-      } else {
-        hs = a_h[i] + kh; ws = a_w[i] + kw;
-        ok = hs >= 0 && ws >= 0 && hs < p.Hs && ws < p.Ws;
-      }
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *(const uint4*)(p.x + ((size_t)(a_base[i] + hs * p.Ws + ws) * p.C + c0 + chunk * 8));
-      ga[i] = v;
+    for (int i = 0; i < GA; ++i) {
+      const unsigned short* src = ((a_mask[i] >> tap) & 1u) ? p.x + (a_off[i] + delta) : zero;
+#ifdef MXDET_ABL_ZEROSRC
+      src = zero;
+#endif
+#ifndef MXDET_ABL_NOLOAD
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(src));
+#endif
     }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (wvalid[i]) v = *(const uint4*)(wrow[i] + (size_t)kt * 64);
-      gb[i] = v;
+    for (int i = 0; i < GB; ++i) {
+      const unsigned short* wsrc = wrow[i] + koff;
+#ifdef MXDET_ABL_ZEROSRC
+      wsrc = zero;
+#endif
+#ifndef MXDET_ABL_NOLOAD
+      __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(wsrc));
+#endif
     }
-  };
-  auto store_tiles = [&](int buf) {
-    uint16_t* sa = smem + buf * STAGE;
-    uint16_t* sb = sa + BM * 64;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) *(uint4*)(sa + lds_off(r0 + 32 * i, chunk)) = ga[i];
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      if (r0 + 32 * i < BN) *(uint4*)(sb + lds_off(r0 + 32 * i, chunk)) = gb[i];
+    // K order = (channel slice, kh, kw) with the TAP fastest: the KH*KW shifted re-reads of one 128-B
+    // activation chunk happen in consecutive steps, while that chunk is still in this XCD's L2
+    ++ld_kt;
+    if (++ld_kw == p.KW) {
+      ld_kw = 0;
+      if (++ld_kh == p.KH) { ld_kh = 0; ld_c0 += 64; }
+    }
   };
 
   f32x4_t acc[MT][NT];
@@ -148,34 +189,64 @@ conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue_stage(s0);
 
   const int frow = lane & 15, fq = lane >> 4;
+  int cur = 0, nxt = NS - 1;
   for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) load_tiles(kt + 1);
+    // stage kt has landed once all but the (NS-2) youngest stages' loads of this wave are done ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (GA + GB)) : "memory");
+    // ... in every wave; the same barrier says every wave is done reading the buffer refilled next
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // Software pipeline inside the step: the fragment reads of BOTH 32-deep halves are issued first (their LDS
+    // latency overlaps the address math / DMA issue of the next stage), then the 2*MT*NT MFMAs run back to back.
     const uint16_t* sa = smem + cur * STAGE;
     const uint16_t* sb = sa + BM * 64;
+    bf16x8_t af0[MT], bf0[NT], af1[MT], bf1[NT];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t af[MT], bfr[NT];
+    for (int i = 0; i < MT; ++i) af0[i] = *(const bf16x8_t*)(sa + lds_off(wm * WTM + i * 16 + frow, fq));
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[i] = *(const bf16x8_t*)(sa + lds_off(wm * WTM + i * 16 + frow, kk * 4 + fq));
+    for (int j = 0; j < NT; ++j) bf0[j] = *(const bf16x8_t*)(sb + lds_off(wn * WTN + j * 16 + frow, fq));
+    issue_stage(nxt);
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af1[i] = *(const bf16x8_t*)(sa + lds_off(wm * WTM + i * 16 + frow, 4 + fq));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf1[j] = *(const bf16x8_t*)(sb + lds_off(wn * WTN + j * 16 + frow, 4 + fq));
+#ifndef MXDET_ABL_NOMFMA
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        bfr[j] = *(const bf16x8_t*)(sb + lds_off(wn * WTN + j * 16 + frow, kk * 4 + fq));
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
+    // interleave: the second half's fragment reads (issued above in program order) are spread between the
+    // first half's MFMAs, 1 ds_read per 2 MFMAs, so LDS traffic and matrix work overlap inside one wave
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    for (int g = 0; g < MT + NT; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
     }
-    if (kt + 1 < KT) store_tiles(cur ^ 1);
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { asm volatile("" ::"v"(af0[i])); asm volatile("" ::"v"(af1[i])); }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { asm volatile("" ::"v"(bf0[j])); asm volatile("" ::"v"(bf1[j])); }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail loads before LDS is re-used
+  __syncthreads();
 
   // ---- epilogue ---------------------------------------------------------------------------------
   float* ep = (float*)smem_raw + wid * 32 * EP_STRIDE;
@@ -250,20 +321,42 @@ conv_igemm_kernel(ConvP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DGRAD>
+static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
+
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
 static int launch_cfg(ConvP& p, hipStream_t s) {
   p.tiles_m = ceil_div(p.M, BM);
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, DGRAD>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD>), dim3((unsigned)nwg), dim3(64 * WM * WN),
+                     0, s, p);
   return check_launch("conv2d");
 }
 
+// Tile choice (measured on MI355X, tools/bench_one_conv.py sweeps, profiles/r01_conv_cfg_sweep.txt): what matters
+// most is having 2-3 workgroups resident per CU so that one workgroup's barrier / LDS-latency / DMA-issue phases
+// overlap another's MFMA phase; a 2-stage ring (48-64 KiB of LDS) allows that, deeper rings do not pay.
 template <bool DGRAD>
 static int launch(ConvP& p, hipStream_t s) {
-  if (p.Ncols <= 16) return launch_cfg<256, 16, 4, 1, DGRAD>(p, s);
-  if (p.Ncols <= 64) return launch_cfg<256, 64, 4, 1, DGRAD>(p, s);
-  return launch_cfg<128, 128, 2, 2, DGRAD>(p, s);
+  const int force = g_force_cfg;
+  const long long t128 = (long long)ceil_div(p.M, 128) * ceil_div(p.Ncols, 128);
+  const long long t64 = (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 128);
+  const int K = p.KH * p.KW * p.C;
+  switch (force) {
+    case 1: return launch_cfg<256, 64, 4, 1, 3, DGRAD>(p, s);
+    case 2: return launch_cfg<256, 128, 4, 2, 3, DGRAD>(p, s);
+    case 3: return launch_cfg<128, 128, 2, 2, 4, DGRAD>(p, s);
+    case 4: return launch_cfg<64, 128, 2, 2, 4, DGRAD>(p, s);
+    case 5: return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
+    case 6: return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
+    case 7: return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+    case 8: return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
+    default: break;
+  }
+  if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
+  if (t128 >= 1536 && K > 256) return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+  if (t64 >= 400) return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
+  return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
 }
 
 static int validate(const mxdet_conv_desc_t* d, const char* who) {
@@ -271,6 +364,7 @@ static int validate(const mxdet_conv_desc_t* d, const char* who) {
   MXDET_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 &&
                     d->stride > 0 && d->pad >= 0,
                 MXDET_ESHAPE, "%s: non-positive dimension", who);
+  MXDET_REQUIRE(d->KH * d->KW <= 25, MXDET_ESHAPE, "%s: at most 25 filter taps (use the stem kernel for 7x7)", who);
   MXDET_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 &&
                     d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
                 MXDET_ESHAPE, "%s: Ho/Wo do not match the convolution arithmetic", who);
@@ -283,6 +377,11 @@ static int validate(const mxdet_conv_desc_t* d, const char* who) {
 }  // namespace mxdet
 
 using namespace mxdet;
+
+extern "C" int mxdet_debug_force_conv_cfg(int32_t cfg) {
+  g_force_cfg = cfg;
+  return MXDET_OK;
+}
 
 extern "C" int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w,
                                 const float* bias, const uint16_t* residual, uint16_t* y,

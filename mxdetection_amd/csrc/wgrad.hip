@@ -46,11 +46,19 @@ wgrad_kernel(WgradP p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][64 * 256];  // [buf][dy|x]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+  // XCD-aware order with the tap fastest: the KH*KW workgroups that share one (dy tile, shifted x tile)
+  // pair sit next to each other in one XCD's queue and hit that XCD's L2 for 8 of 9 reads.
   int b = blockIdx.x;
-  const int ks = b % p.ksplit; b /= p.ksplit;
+  {
+    const int nwg = gridDim.x;
+    int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntaps = p.KH * p.KW;
+  const int tap = b % ntaps; b /= ntaps;
   const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
   const int co_t = b % p.co_tiles; b /= p.co_tiles;
-  const int tap = b;
+  const int ks = b;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = co_t * 128, ci0 = ci_t * 128;
 
