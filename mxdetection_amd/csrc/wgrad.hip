@@ -30,6 +30,10 @@ struct WgradP {
   int co_tiles, ci_tiles, ksplit, steps_per_split;
 };
 
+// 16 bytes of zeros read by out-of-range lanes, so that every global load is unconditional (a branch around a
+// load makes hipcc wait for each load separately: 8 serialized round trips per step)
+__device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero[64];
+
 // byte offset inside a [64 px][256 B] image of 16-B chunk c16 of pixel row `row`
 __device__ __forceinline__ int wg_off(int row, int c16) {
   int f = (row & 3) | (((row >> 3) & 1) << 2);
@@ -41,10 +45,18 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* lds_base, int by
       (__attribute__((address_space(3))) s16x4_t*)(lds_base + byte_off));
 }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One workgroup = one 128(co) x 128(ci) tile of one tap over a range of 64-pixel steps. Global -> LDS is a
+// 2-stage LDS-DMA ring (global_load_lds_dwordx4, 1 KiB per wave instruction = 4 pixel rows x 256 B): the loads
+// of step t+1 are in flight while step t is multiplied; one s_waitcnt vmcnt(0) + one raw s_barrier per step.
+// The LDS image is lane-linear, so the granule swizzle is applied to the per-lane SOURCE chunk.
 __global__ void __launch_bounds__(256)
 wgrad_kernel(WgradP p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][64 * 256];  // [buf][dy|x]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][64 * 256];  // [buf][dy|x]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   // XCD-aware order with the tap fastest: the KH*KW workgroups that share one (dy tile, shifted x tile)
   // pair sit next to each other in one XCD's queue and hit that XCD's L2 for 8 of 9 reads.
@@ -62,39 +74,47 @@ wgrad_kernel(WgradP p) {
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = co_t * 128, ci0 = ci_t * 128;
 
-  const int c16 = tid & 15, r0 = tid >> 4;   // 16 threads per pixel row, 16 rows per pass, 4 passes
-  const bool co_ok = (co0 + c16 * 8) < p.Cout;
-  const bool ci_ok = (ci0 + c16 * 8) < p.Cin;
   const int step0 = ks * p.steps_per_split;
   int nsteps = ceil_div(p.M, 64) - step0;
   nsteps = nsteps > p.steps_per_split ? p.steps_per_split : nsteps;
 
-  uint4 gy[4], gx[4];
-  auto load_tiles = [&](int step) {
-    int mbase = (step0 + step) * 64;
+  // DMA geometry: wave w, instruction i (0..3) fills pixel rows 4*(4w+i) .. +3 of both images; lane l covers
+  // row (l>>4), physical 16-B slot (l&15), i.e. logical chunk ((slot>>1) ^ f(row)) * 2 + (slot & 1)
+  const int lrow = lane >> 4, lslot = lane & 15;
+  const uint16_t* zero = (const uint16_t*)g_wgrad_zero;
+  const int HW = p.Ho * p.Wo;
+  const int dq = 64 / p.Wo, dr = 64 - dq * p.Wo;     // 64 pixels = dq rows + dr columns
+  int c_img[4], c_ho[4], c_wo[4], c_m[4], c_chunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (wid * 4 + i) * 4 + lrow;
+    int f = (row & 3) | (((row >> 3) & 1) << 2);
+    c_chunk[i] = ((((lslot >> 1) ^ f) << 1) | (lslot & 1)) * 8;     // first channel of this lane's 16 bytes
+    int m = step0 * 64 + row;
+    c_m[i] = m;
+    c_img[i] = m / HW;
+    int rem = m - c_img[i] * HW;
+    c_ho[i] = rem / p.Wo;
+    c_wo[i] = rem - c_ho[i] * p.Wo;
+  }
+  auto issue_stage = [&](int buf, bool live) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int m = mbase + r0 + 16 * i;
-      uint4 vy = make_uint4(0u, 0u, 0u, 0u), vx = make_uint4(0u, 0u, 0u, 0u);
-      if (m < p.M) {
-        if (co_ok) vy = *(const uint4*)(p.dy + (size_t)m * p.Cout + co0 + c16 * 8);
-        int img = m / (p.Ho * p.Wo);
-        int rem = m - img * (p.Ho * p.Wo);
-        int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-        if (ci_ok && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W)
-          vx = *(const uint4*)(p.x + ((size_t)(img * p.H + hi) * p.W + wi) * p.Cin + ci0 + c16 * 8);
-      }
-      gy[i] = vy;
-      gx[i] = vx;
-    }
-  };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int off = wg_off(r0 + 16 * i, c16);
-      *(uint4*)(smem[buf][0] + off) = gy[i];
-      *(uint4*)(smem[buf][1] + off) = gx[i];
+      const bool mok = live && c_m[i] < p.M;
+      const int hi = c_ho[i] * p.stride - p.pad + kh, wi = c_wo[i] * p.stride - p.pad + kw;
+      const bool yok = mok && (co0 + c_chunk[i]) < p.Cout;
+      const bool xok = mok && (ci0 + c_chunk[i]) < p.Cin && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
+      const uint16_t* py = yok ? p.dy + ((size_t)c_m[i] * p.Cout + co0 + c_chunk[i]) : zero;
+      const uint16_t* px = xok ? p.x + (((size_t)(c_img[i] * p.H + hi) * p.W + wi) * p.Cin + ci0 + c_chunk[i]) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(smem[buf][0] + (wid * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(smem[buf][1] + (wid * 4 + i) * 1024), 16, 0, 0);
+      // advance this row by 64 pixels
+      c_m[i] += 64;
+      c_wo[i] += dr;
+      c_ho[i] += dq;
+      if (c_wo[i] >= p.Wo) { c_wo[i] -= p.Wo; ++c_ho[i]; }
+      if (HW == 1) { c_img[i] += c_ho[i]; c_ho[i] = 0; }          // fully connected: one pixel per "image"
+      else if (c_ho[i] >= p.Ho) { int k = c_ho[i] / p.Ho; c_ho[i] -= k * p.Ho; c_img[i] += k; }
     }
   };
 
@@ -108,14 +128,13 @@ wgrad_kernel(WgradP p) {
   // 16-channel block; it receives channel (lane&15) of those four pixel rows.
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 
-  if (nsteps > 0) {
-    load_tiles(0);
-    store_tiles(0);
-  }
-  __syncthreads();
+  issue_stage(0, nsteps > 0);
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) load_tiles(st + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's loads of step st have landed ...
+    __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done with the other buffer
+    asm volatile("" ::: "memory");
+    issue_stage(cur ^ 1, st + 1 < nsteps);
     const unsigned char* sy = smem[cur][0];
     const unsigned char* sx = smem[cur][1];
 #pragma unroll
@@ -125,12 +144,12 @@ wgrad_kernel(WgradP p) {
       const int fa = (rowa & 3) | (((rowa >> 3) & 1) << 2);
       const int fb = (rowb & 3) | (((rowb >> 3) & 1) << 2);
       bf16x8_t af[4], bfr[4];
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int cgi = wm * 4 + i;   // 16-channel granule of the co tile
         s16x4_t lo = tr_read(sy, rowa * 256 + ((cgi ^ fa) << 5) + pp * 8);
         s16x4_t hi = tr_read(sy, rowb * 256 + ((cgi ^ fb) << 5) + pp * 8);
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
         s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[i] = __builtin_bit_cast(bf16x8_t, v);
       }
@@ -139,7 +158,6 @@ wgrad_kernel(WgradP p) {
         int cgj = wn * 4 + j;
         s16x4_t lo = tr_read(sx, rowa * 256 + ((cgj ^ fa) << 5) + pp * 8);
         s16x4_t hi = tr_read(sx, rowb * 256 + ((cgj ^ fb) << 5) + pp * 8);
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
         s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bfr[j] = __builtin_bit_cast(bf16x8_t, v);
       }
@@ -149,9 +167,8 @@ wgrad_kernel(WgradP p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (st + 1 < nsteps) store_tiles(cur ^ 1);
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // slab[ks][co][tap][ci]; D layout: col = lane&15 -> ci, row = (lane>>4)*4 + r -> co
   const size_t Ktot = (size_t)p.KH * p.KW * p.Cin;
