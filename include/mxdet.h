@@ -252,6 +252,12 @@ int mxdet_debug_force_conv_cfg(int32_t cfg);
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);
 
+/* All filters of a model in one launch. descs_dev: device array of ndesc records
+ * { const uint16_t* w; uint16_t* wt; int32 Cout, taps, Cin, tile0; } (32 bytes each) where tile0 is the running
+ * sum of ceil(Cin/32)*ceil(Cout/32)*taps over the preceding records, total_tiles the overall sum. */
+int mxdet_filter_transpose_batched(const void* descs_dev, int32_t ndesc, int32_t total_tiles,
+                                   mxdet_stream_t stream);
+
 /* stem: 7x7 stride-2 pad-3 convolution reading the NCHW fp32/bf16 image [N,3,H,W] directly
  * (coalesced plane reads), + bias + ReLU, writing bf16 [N,Ho,Wo,64]; w bf16 [64,7,7,3]. */
 int mxdet_stem_conv7x7(const void* image, int32_t dtype, int32_t N, int32_t H, int32_t W,

@@ -34,10 +34,23 @@ __device__ __forceinline__ float pyr_score(const PyramidDev& p, int l, int n, in
   return load_as_f32(p.cls[l], off, p.dtype);
 }
 
+// (0) gather the objectness logits (arbitrary strides, e.g. 3 channels of a 64-channel padded row) into a dense
+// [N][A_total] array of order-preserving keys, in parallel over the whole chip: the selection passes of (1)
+// then stream 4 dense bytes per anchor instead of touching a 128-B line per cell from a single CU.
+__global__ void proposal_gather_kernel(PyramidDev p, int N, long long A_total, unsigned* __restrict__ fkeys) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)N * A_total) return;
+  int n = (int)(idx / A_total);
+  long long g = idx - (long long)n * A_total;
+  int l = 0;
+  while (l + 1 < p.num_levels && g >= p.level_offset[l + 1]) ++l;
+  fkeys[idx] = mxdet_float_key(pyr_score(p, l, n, (int)(g - p.level_offset[l])));
+}
+
 // (1) top-k per (level, image). keys out: (float_key(score) << 32) | (0xFFFFFFFF - global_index)
 __global__ void __launch_bounds__(1024)
-proposal_topk_kernel(PyramidDev p, int pre_n, int Kpad, unsigned long long* __restrict__ keys,
-                     int32_t* __restrict__ counts) {
+proposal_topk_kernel(PyramidDev p, long long A_total, const unsigned* __restrict__ fkeys, int pre_n, int Kpad,
+                     unsigned long long* __restrict__ keys, int32_t* __restrict__ counts) {
   __shared__ SelectSmem sm;
   __shared__ unsigned long long list[kMaxPre];
   __shared__ int n_sel;
@@ -50,15 +63,14 @@ proposal_topk_kernel(PyramidDev p, int pre_n, int Kpad, unsigned long long* __re
   const int nbits = (p.dtype == MXDET_DTYPE_BF16) ? 16 : 32;
   const unsigned keymask = (nbits == 16) ? 0xffff0000u : 0xffffffffu;
   const unsigned goff = (unsigned)p.level_offset[l];
+  const unsigned* fk_l = fkeys + (long long)n * A_total + p.level_offset[l];
   auto keyf = [&](int i, unsigned& kv) -> bool {
-    float s = pyr_score(p, l, n, i);
-    kv = (~mxdet_float_key(s)) & keymask;
+    kv = (~fk_l[i]) & keymask;
     return true;
   };
   SelectResult sel = block_select_threshold(nl, pre_n, nbits, keyf, sm);
   for (int i = threadIdx.x; i < nl; i += blockDim.x) {
-    float sc = pyr_score(p, l, n, i);
-    unsigned fk = mxdet_float_key(sc);
+    unsigned fk = fk_l[i];
     if (sel.chosen((~fk) & keymask, (unsigned)i)) {
       int pos = atomicAdd(&n_sel, 1);
       list[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
@@ -175,6 +187,7 @@ proposal_merge_kernel(int L, int pre_n, int lvl_cap, int post_n,
 }
 
 struct ProposalWs {
+  unsigned* fkeys;
   unsigned long long* keys;
   int32_t* counts;
   float4* boxes;
@@ -186,7 +199,7 @@ struct ProposalWs {
   size_t total;
 };
 
-static ProposalWs carve(void* base, int B, int pre_n) {
+static ProposalWs carve(void* base, int B, int pre_n, int N, long long A_total) {
   ProposalWs w;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -195,6 +208,7 @@ static ProposalWs carve(void* base, int B, int pre_n) {
     return o;
   };
   char* p = (char*)base;
+  w.fkeys = (unsigned*)(p + take((size_t)N * A_total * 4));
   w.keys = (unsigned long long*)(p + take((size_t)B * pre_n * 8));
   w.counts = (int32_t*)(p + take((size_t)B * 4));
   w.boxes = (float4*)(p + take((size_t)B * pre_n * 16));
@@ -214,7 +228,9 @@ using namespace mxdet;
 extern "C" size_t mxdet_proposal_workspace_bytes(const mxdet_pyramid_t* p, int32_t N,
                                                  int32_t pre_nms_top_n) {
   if (!p || N <= 0 || pre_nms_top_n <= 0 || p->num_levels <= 0) return 0;
-  return carve(nullptr, N * p->num_levels, pre_nms_top_n).total;
+  long long At = 0;
+  for (int l = 0; l < p->num_levels; ++l) At += (long long)p->H[l] * p->W[l] * p->A;
+  return carve(nullptr, N * p->num_levels, pre_nms_top_n, N, At).total;
 }
 
 extern "C" int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* im_info,
@@ -235,7 +251,9 @@ extern "C" int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* 
   MXDET_REQUIRE(im_info && rois && roi_scores && roi_anchor && num_rois, MXDET_EINVAL,
                 "proposal: null pointer");
   const int L = p->num_levels, B = N * L;
-  ProposalWs w = carve(workspace, B, pre_nms_top_n);
+  long long A_total = 0;
+  for (int l = 0; l < L; ++l) A_total += (long long)p->H[l] * p->W[l] * p->A;
+  ProposalWs w = carve(workspace, B, pre_nms_top_n, N, A_total);
   MXDET_REQUIRE(workspace && workspace_bytes >= w.total, MXDET_EWORKSPACE,
                 "proposal: workspace %zu < %zu", workspace_bytes, w.total);
   int per_level_post = post_nms_top_n < pre_nms_top_n ? post_nms_top_n : pre_nms_top_n;
@@ -262,8 +280,10 @@ extern "C" int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* 
   int Kpad = 1;
   while (Kpad < pre_nms_top_n) Kpad <<= 1;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(proposal_topk_kernel, dim3(L, N), dim3(1024), 0, s, d, pre_nms_top_n, Kpad,
-                     w.keys, w.counts);
+  hipLaunchKernelGGL(proposal_gather_kernel, dim3((unsigned)ceil_div<long long>((long long)N * A_total, 256)),
+                     dim3(256), 0, s, d, N, A_total, w.fkeys);
+  hipLaunchKernelGGL(proposal_topk_kernel, dim3(L, N), dim3(1024), 0, s, d, A_total, (const unsigned*)w.fkeys,
+                     pre_nms_top_n, Kpad, w.keys, w.counts);
   int tot = B * pre_nms_top_n;
   hipLaunchKernelGGL(proposal_decode_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, s, d, N,
                      pre_nms_top_n, im_info, min_size, w.keys, w.counts, w.boxes, w.invalid);

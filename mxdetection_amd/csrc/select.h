@@ -33,8 +33,13 @@ struct SelectResult {
 
 // keyf(i, key&) -> bool : is element i a candidate, and its key (smaller = preferred). Only the top
 // `nbits` (16 or 32) bits of keys may be non-zero. All threads must call with the same arguments.
-template <class KeyF>
-__device__ inline SelectResult block_select_threshold(int n, int k, int nbits, KeyF keyf, SelectSmem& sm) {
+// idxf(i) -> the index used for tie-breaking (defaults to the position i; compacted candidate lists pass the
+// original element index so that the result does not depend on the order of the list).
+struct IdentityIdx { __device__ __forceinline__ unsigned operator()(int i) const { return (unsigned)i; } };
+
+template <class KeyF, class IdxF = IdentityIdx>
+__device__ inline SelectResult block_select_threshold(int n, int k, int nbits, KeyF keyf, SelectSmem& sm,
+                                                      IdxF idxf = IdxF()) {
   const int tid = threadIdx.x, nt = blockDim.x;
   SelectResult res;
   res.T = 0; res.IT = 0xffffffffu; res.mode = 0; res.n_cand = 0;
@@ -97,7 +102,8 @@ __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, K
     __syncthreads();
     for (int i = tid; i < n; i += nt) {
       unsigned kv;
-      if (((unsigned)i & im) == ip && keyf(i, kv) && kv == T) atomicAdd(&sm.hist[((unsigned)i >> shift) & 255u], 1u);
+      const unsigned ix = idxf(i);
+      if ((ix & im) == ip && keyf(i, kv) && kv == T) atomicAdd(&sm.hist[(ix >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid == 0) {

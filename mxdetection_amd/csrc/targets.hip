@@ -49,13 +49,49 @@ anchor_iou_kernel(const float4* __restrict__ anchors, long long A_total, const f
     if (sgm[g] != 0u) atomicMax(&gt_max[(long long)n * G_max + g], sgm[g]);
 }
 
+// Candidate compaction for the sampler: every foreground anchor and every background anchor whose Philox key is
+// below kBgKeyCut (expected ~3 % of them) is appended to a per-image list, in parallel. The sampler then selects
+// among a few thousand entries instead of scanning 268k anchors 8 times from one CU; if a list overflows or the
+// filtered background list is shorter than the number wanted, it falls back to the full scan (same result).
+constexpr int kCandCap = 16384;
+constexpr unsigned kBgKeyCut = 0x08000000u;   // 2^32 / 32
+struct CandLists {
+  unsigned* key;   // [N][2][kCandCap]
+  int* idx;        // [N][2][kCandCap]
+  int* count;      // [N][4]: appended fg, appended bg, total fg, total bg
+};
+// Wave-aggregated append: one atomic per wave and stream. Must be called by every lane of the wave
+// (lab < 0 = nothing to append). count[n*4+0] ends up as the number of ALL foreground anchors, count[n*4+1] as
+// the number of background anchors below the key cut (both may exceed kCandCap: then the list is incomplete).
+__device__ __forceinline__ void cand_append(const CandLists& c, int n, int lab, unsigned key, int a) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const bool want = (st == 0) ? (lab == 1) : (lab == 0 && key < kBgKeyCut);
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) continue;
+    const int lane = lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&c.count[n * 4 + st], __popcll(m));
+    base = __shfl(base, leader);
+    if (want) {
+      const unsigned long long below = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
+      const int pos = base + __popcll(below);
+      if (pos < kCandCap) {
+        c.key[((long long)n * 2 + st) * kCandCap + pos] = key;
+        c.idx[((long long)n * 2 + st) * kCandCap + pos] = a;
+      }
+    }
+  }
+}
+
 // stage 2: labels before sampling
 __global__ void __launch_bounds__(256)
 anchor_label_kernel(const float4* __restrict__ anchors, long long A_total, const float* __restrict__ gt,
                     int G_max, const float* __restrict__ max_iou, const unsigned* __restrict__ gt_max,
                     float fg_thresh, float bg_thresh, unsigned seed, unsigned step,
                     const unsigned* __restrict__ step_dev, unsigned image_offset,
-                    int32_t* __restrict__ labels, unsigned* __restrict__ keys) {
+                    int32_t* __restrict__ labels, unsigned* __restrict__ keys, CandLists cand) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sg = (float*)smem_raw;
   unsigned* sgm = (unsigned*)(sg + G_max * 5);
@@ -64,8 +100,8 @@ anchor_label_kernel(const float4* __restrict__ anchors, long long A_total, const
   for (int i = threadIdx.x; i < G_max; i += blockDim.x) sgm[i] = gt_max[(long long)n * G_max + i];
   __syncthreads();
   long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A_total) return;
-  float m = max_iou[(long long)n * A_total + a];
+  const bool in_range = a < A_total;
+  float m = in_range ? max_iou[(long long)n * A_total + a] : -1.0f;
   int lab = -1;
   if (m >= 0.0f) {  // inside the image and at least one valid GT (m = -1 otherwise)
     if (m < bg_thresh) lab = 0;
@@ -79,11 +115,14 @@ anchor_label_kernel(const float4* __restrict__ anchors, long long A_total, const
       }
     }
   }
-  labels[(long long)n * A_total + a] = lab;
   // sampling key of this anchor in its stream (0 = fg, 1 = bg), computed once, in parallel
   if (step_dev) step = *step_dev;
-  keys[(long long)n * A_total + a] =
-      lab >= 0 ? mxdet_sample_key(seed, step, image_offset + (unsigned)n, lab == 1 ? 0u : 1u, (unsigned)a) : 0u;
+  unsigned key = lab >= 0 ? mxdet_sample_key(seed, step, image_offset + (unsigned)n, lab == 1 ? 0u : 1u, (unsigned)a) : 0u;
+  if (in_range) {
+    labels[(long long)n * A_total + a] = lab;
+    keys[(long long)n * A_total + a] = key;
+  }
+  if (cand.count != nullptr) cand_append(cand, n, lab, key, (int)a);   // wave-uniform call
 }
 
 // An inside anchor of an image with no valid GT has max_iou = -1 above; the lineage labels those
@@ -93,7 +132,7 @@ anchor_nogt_kernel(const float4* __restrict__ anchors, long long A_total, const 
                    int G_max, const float* __restrict__ im_info, float allowed_border, unsigned seed,
                    unsigned step, const unsigned* __restrict__ step_dev, unsigned image_offset,
                    int32_t* __restrict__ labels, float* __restrict__ max_iou,
-                   unsigned* __restrict__ keys) {
+                   unsigned* __restrict__ keys, CandLists cand) {
   const int n = blockIdx.y;
   __shared__ int any;
   if (threadIdx.x == 0) any = 0;
@@ -101,19 +140,24 @@ anchor_nogt_kernel(const float4* __restrict__ anchors, long long A_total, const 
   for (int g = threadIdx.x; g < G_max; g += blockDim.x)
     if (gt[((long long)n * G_max + g) * 5 + 4] >= 0.0f) any = 1;
   __syncthreads();
-  if (any) return;
+  if (any) return;   // block-uniform
   long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A_total) return;
-  float4 b = anchors[a];
-  float im_h = im_info[n * 3 + 0], im_w = im_info[n * 3 + 1];
-  bool inside = (b.x >= -allowed_border) && (b.y >= -allowed_border) &&
-                (b.z < im_w + allowed_border) && (b.w < im_h + allowed_border);
+  bool inside = false;
+  if (a < A_total) {
+    float4 b = anchors[a];
+    float im_h = im_info[n * 3 + 0], im_w = im_info[n * 3 + 1];
+    inside = (b.x >= -allowed_border) && (b.y >= -allowed_border) && (b.z < im_w + allowed_border) &&
+             (b.w < im_h + allowed_border);
+  }
+  if (step_dev) step = *step_dev;
+  unsigned key = 0u;
   if (inside) {
-    if (step_dev) step = *step_dev;
+    key = mxdet_sample_key(seed, step, image_offset + (unsigned)n, 1u, (unsigned)a);
     labels[(long long)n * A_total + a] = 0;
     max_iou[(long long)n * A_total + a] = 0.0f;
-    keys[(long long)n * A_total + a] = mxdet_sample_key(seed, step, image_offset + (unsigned)n, 1u, (unsigned)a);
+    keys[(long long)n * A_total + a] = key;
   }
+  if (cand.count != nullptr) cand_append(cand, n, inside ? 0 : -1, key, (int)a);
 }
 
 // stage 3: per-image selection thresholds (one 1024-thread workgroup per image). The k smallest
@@ -122,17 +166,40 @@ struct AnchorSel { unsigned T[2], IT[2]; int mode[2]; };
 
 __global__ void __launch_bounds__(1024)
 anchor_sample_kernel(long long A_total, int batch_size, int max_fg, const int32_t* __restrict__ labels,
-                     const unsigned* __restrict__ keys, AnchorSel* __restrict__ sel) {
+                     const unsigned* __restrict__ keys, CandLists cand, AnchorSel* __restrict__ sel) {
   __shared__ SelectSmem sm;
   const int n = blockIdx.x;
   const int32_t* lab = labels + (long long)n * A_total;
   const unsigned* key = keys + (long long)n * A_total;
   const int A = (int)A_total;
-  auto kfg = [&](int i, unsigned& kv) -> bool { kv = key[i]; return lab[i] == 1; };
-  auto kbg = [&](int i, unsigned& kv) -> bool { kv = key[i]; return lab[i] == 0; };
-  SelectResult rf = block_select_threshold(A, max_fg, 32, kfg, sm);
-  int nfg = rf.n_cand < max_fg ? rf.n_cand : max_fg;
-  SelectResult rb = block_select_threshold(A, batch_size - nfg, 32, kbg, sm);
+  const int n_fg_list = cand.count[n * 4 + 0], n_bg_list = cand.count[n * 4 + 1];
+  const int n_fg_all = n_fg_list;   // every foreground anchor is appended (count keeps counting past the cap)
+  const unsigned* fk = cand.key + ((long long)n * 2 + 0) * kCandCap;
+  const unsigned* bk = cand.key + ((long long)n * 2 + 1) * kCandCap;
+  const int* fi = cand.idx + ((long long)n * 2 + 0) * kCandCap;
+  const int* bi = cand.idx + ((long long)n * 2 + 1) * kCandCap;
+  SelectResult rf, rb;
+  if (n_fg_list <= kCandCap) {   // complete list of foreground anchors
+    auto kf = [&](int i, unsigned& kv) -> bool { kv = fk[i]; return true; };
+    auto xf = [&](int i) -> unsigned { return (unsigned)fi[i]; };
+    rf = block_select_threshold(n_fg_list, max_fg, 32, kf, sm, xf);
+  } else {
+    auto kf = [&](int i, unsigned& kv) -> bool { kv = key[i]; return lab[i] == 1; };
+    rf = block_select_threshold(A, max_fg, 32, kf, sm);
+  }
+  const int nfg = n_fg_all < max_fg ? n_fg_all : max_fg;
+  const int want_bg = batch_size - nfg;
+  // the filtered list holds exactly the background anchors with key < kBgKeyCut: if it has at least want_bg
+  // entries, the want_bg smallest keys overall are all inside it
+  if (n_bg_list <= kCandCap && n_bg_list >= want_bg) {
+    auto kb = [&](int i, unsigned& kv) -> bool { kv = bk[i]; return true; };
+    auto xb = [&](int i) -> unsigned { return (unsigned)bi[i]; };
+    rb = block_select_threshold(n_bg_list, want_bg, 32, kb, sm, xb);
+    if (rb.mode == 1) { rb.mode = 0; rb.T = kBgKeyCut - 1u; rb.IT = 0xffffffffu; }   // "all of the list", not all bg
+  } else {
+    auto kb = [&](int i, unsigned& kv) -> bool { kv = key[i]; return lab[i] == 0; };
+    rb = block_select_threshold(A, want_bg, 32, kb, sm);
+  }
   if (threadIdx.x == 0) {
     AnchorSel o;
     o.T[0] = rf.T; o.IT[0] = rf.IT; o.mode[0] = rf.mode;
@@ -324,6 +391,8 @@ struct AnchorWs {
   float* max_iou;
   unsigned* keys;
   AnchorSel* sel;
+  CandLists cand;
+  size_t cand_count_bytes;
   size_t total;
 };
 static AnchorWs carve_anchor(void* base, int N, long long A_total, int G_max) {
@@ -336,6 +405,10 @@ static AnchorWs carve_anchor(void* base, int N, long long A_total, int G_max) {
   w.max_iou = (float*)(p + take((size_t)N * A_total * 4));
   w.keys = (unsigned*)(p + take((size_t)N * A_total * 4));
   w.sel = (AnchorSel*)(p + take((size_t)N * sizeof(AnchorSel)));
+  w.cand.key = (unsigned*)(p + take((size_t)N * 2 * kCandCap * 4));
+  w.cand.idx = (int*)(p + take((size_t)N * 2 * kCandCap * 4));
+  w.cand_count_bytes = align_up((size_t)N * 4 * sizeof(int), 16);
+  w.cand.count = (int*)(p + take(w.cand_count_bytes));
   w.total = off;
   return w;
 }
@@ -370,6 +443,10 @@ extern "C" int mxdet_anchor_target(const float* anchors, int64_t A_total, const 
   float* miou = max_iou ? max_iou : w.max_iou;
   hipError_t e = hipMemsetAsync(w.gt_max, 0, (size_t)N * G_max * 4, s);
   MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "anchor_target: memset failed");
+  e = hipMemsetAsync(w.cand.count, 0, w.cand_count_bytes, s);
+  MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "anchor_target: memset failed");
+  CandLists cl = w.cand;
+  if (batch_size <= 0) cl.count = nullptr;   // no sampling: no candidate lists
   dim3 grid((unsigned)ceil_div<long long>(A_total, 256), N);
   size_t lds = (size_t)G_max * 6 * 4;
   hipLaunchKernelGGL(anchor_iou_kernel, grid, dim3(256), lds, s, (const float4*)anchors,
@@ -377,14 +454,14 @@ extern "C" int mxdet_anchor_target(const float* anchors, int64_t A_total, const 
                      w.gt_max);
   hipLaunchKernelGGL(anchor_label_kernel, grid, dim3(256), lds, s, (const float4*)anchors,
                      (long long)A_total, gt_boxes, G_max, miou, w.gt_max, fg_thresh, bg_thresh, seed,
-                     step, step_dev, image_offset, labels, w.keys);
+                     step, step_dev, image_offset, labels, w.keys, cl);
   hipLaunchKernelGGL(anchor_nogt_kernel, grid, dim3(256), 0, s, (const float4*)anchors,
                      (long long)A_total, gt_boxes, G_max, im_info, allowed_border, seed, step, step_dev,
-                     image_offset, labels, miou, w.keys);
+                     image_offset, labels, miou, w.keys, cl);
   if (batch_size > 0) {
     int max_fg = (int)(fg_fraction * (float)batch_size);
     hipLaunchKernelGGL(anchor_sample_kernel, dim3(N), dim3(1024), 0, s, (long long)A_total,
-                       batch_size, max_fg, (const int32_t*)labels, (const unsigned*)w.keys, w.sel);
+                       batch_size, max_fg, (const int32_t*)labels, (const unsigned*)w.keys, cl, w.sel);
   }
   hipLaunchKernelGGL(anchor_encode_kernel, grid, dim3(256), 0, s, (const float4*)anchors,
                      (long long)A_total, gt_boxes, G_max, labels, amax, (const unsigned*)w.keys,

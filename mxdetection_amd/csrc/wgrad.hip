@@ -234,13 +234,22 @@ colsum_partial_kernel(const uint16_t* __restrict__ dy, int M, int C, int rows_pe
     partial[(size_t)blockIdx.x * C + c] = t;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C,
-                                    int accumulate, float* __restrict__ db) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 channels x 4 partial-lanes per workgroup; lanes summed in fixed order -> deterministic
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C, int accumulate,
+                    float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) t += partial[(size_t)b * C + c];
-  db[c] = accumulate ? db[c] + t : t;
+  if (c < C)
+    for (int b = part; b < nblocks; b += 4) t += partial[(size_t)b * C + c];
+  red[part][cl] = t;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    float v = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    db[c] = accumulate ? db[c] + v : v;
+  }
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]
@@ -259,6 +268,37 @@ __global__ void filter_transpose_kernel(const uint16_t* __restrict__ w, int Cout
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     int ci = ci0 + r, co = co0 + threadIdx.x;
     if (co < Cout && ci < Cin) wt[((size_t)ci * taps + tap) * Cout + co] = tile[threadIdx.x][r];
+  }
+}
+
+// batched form: one launch for every filter of the model (descriptor table in device memory)
+struct TransposeDesc { const uint16_t* w; uint16_t* wt; int Cout, taps, Cin, tile0; };
+__global__ void filter_transpose_batched_kernel(const TransposeDesc* __restrict__ descs, int ndesc) {
+  __shared__ uint16_t tile[32][33];
+  // binary search the descriptor that owns this tile
+  int lo = 0, hi = ndesc - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const TransposeDesc d = descs[lo];
+  int t = b - d.tile0;
+  const int tiles_ci = (d.Cin + 31) >> 5, tiles_co = (d.Cout + 31) >> 5;
+  const int tci = t % tiles_ci; t /= tiles_ci;
+  const int tco = t % tiles_co; t /= tiles_co;
+  const int tap = t;
+  const int ci0 = tci * 32, co0 = tco * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int co = co0 + r, ci = ci0 + threadIdx.x;
+    uint16_t v = 0;
+    if (co < d.Cout && ci < d.Cin) v = d.w[((size_t)co * d.taps + tap) * d.Cin + ci];
+    tile[r][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int ci = ci0 + r, co = co0 + threadIdx.x;
+    if (co < d.Cout && ci < d.Cin) d.wt[((size_t)ci * d.taps + tap) * d.Cout + co] = tile[threadIdx.x][r];
   }
 }
 
@@ -345,10 +385,20 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
     size_t lds = (size_t)RL * d->Cout * sizeof(float);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(w.colsum_blocks), dim3(256), lds, s, dy, p.M, d->Cout,
                        w.colsum_rows, partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d->Cout, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d->Cout, 64)), dim3(256), 0, s,
                        (const float*)partial, w.colsum_blocks, d->Cout, d->accumulate, db);
   }
   return check_launch("conv2d_wgrad");
+}
+
+extern "C" int mxdet_filter_transpose_batched(const void* descs_dev, int32_t ndesc, int32_t total_tiles,
+                                              mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(ndesc > 0 && total_tiles > 0, MXDET_ESHAPE, "filter_transpose_batched: empty table");
+  MXDET_REQUIRE(descs_dev != nullptr, MXDET_EINVAL, "filter_transpose_batched: null pointer");
+  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3(total_tiles), dim3(32, 8), 0, as_stream(stream),
+                     (const TransposeDesc*)descs_dev, ndesc);
+  return check_launch("filter_transpose_batched");
 }
 
 extern "C" int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW,

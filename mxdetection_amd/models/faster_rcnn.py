@@ -73,8 +73,12 @@ class FasterRCNN:
         return sum(e[3] for e in self.arena.entries)
 
     def refresh_transposed(self):
-        for l in self.layers:
-            l.refresh_transposed()
+        """[Cout,KH,KW,Cin] -> [Cin,KH,KW,Cout] copies for dgrad: one batched launch for all trainable filters."""
+        from ..ops import dense
+        if getattr(self, "_tr_table", None) is None:
+            pairs = [(l.w_bf16, l.wt) for l in self.layers if l.trainable]
+            self._tr_table = dense.make_transpose_table(pairs, self.device)
+        dense.filter_transpose_batched(*self._tr_table)
 
     def enable_data_parallel(self, world_size):
         import torch.distributed as dist

@@ -75,6 +75,24 @@ def filter_transpose(w, out=None):
     return out
 
 
+def make_transpose_table(pairs, device):
+    """pairs: list of (w [Cout,KH,KW,Cin] bf16, wt [Cin,KH,KW,Cout] bf16). Returns (device table, ndesc, total_tiles)."""
+    import struct
+    buf = bytearray()
+    tile0 = 0
+    for w, wt in pairs:
+        Cout, KH, KW, Cin = w.shape
+        buf += struct.pack("<QQiiii", w.data_ptr(), wt.data_ptr(), Cout, KH * KW, Cin, tile0)
+        tile0 += ((Cin + 31) // 32) * ((Cout + 31) // 32) * KH * KW
+    table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
+    return table, len(pairs), tile0
+
+
+def filter_transpose_batched(table, ndesc, total_tiles):
+    check(_lib.load().mxdet_filter_transpose_batched(ptr(table), ndesc, total_tiles, stream_ptr()),
+          "filter_transpose_batched")
+
+
 def stem_conv7x7(image, w, bias=None, out=None):
     """image: NCHW [N,3,H,W] f32|bf16; w bf16 [64,7,7,3]; returns bf16 [N,Ho,Wo,64] (conv + bias + ReLU)."""
     lib = _lib.load()

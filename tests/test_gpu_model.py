@@ -53,7 +53,7 @@ def test_loss_decreases_on_a_fixed_batch(hip):
     m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
     hist = []
     for it in range(12):
-        rpn, rcnn = m.train_step(image, gt, im_info, step=0, image_offset=0, lr=0.01)
+        rpn, rcnn = m.train_step(image, gt, im_info, step=0, image_offset=0, lr=0.002)
         hist.append(float((rpn.sum() + rcnn.sum()).item()))
     assert np.all(np.isfinite(hist)), hist
     assert hist[-1] < 0.8 * hist[0], hist
