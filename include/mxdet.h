@@ -211,6 +211,25 @@ int mxdet_rcnn_loss(const void* cls_logits, const void* bbox_pred, int32_t dtype
                     void* grad_reg, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * core/mask + mask_heads (README.md:18, :30) -- Mask R-CNN.
+ * mask targets: for roi r (batch, box) with matched GT g = matched_gt[r] and class labels[r] > 0, resample the
+ * instance bitmask gt_masks[batch, g] ([N,G_max,H,W] u8, 0/1) inside the box to S x S (bilinear at bin centres,
+ * RoIAlign aligned=False tap rules) and threshold at 0.5. cls_out[r] = class (1..) or -1 for non-foreground rois. */
+int mxdet_mask_target(const float* rois, const int32_t* matched_gt, const int32_t* labels,
+                      const uint8_t* gt_masks, int64_t R, int32_t G_max, int32_t H, int32_t W, int32_t S,
+                      uint8_t* targets, int32_t* cls_out, mxdet_stream_t stream);
+/* x [R,H,W,4*C] (channel = (dy*2+dx)*C + c) -> y [R,2H,2W,C] (inverse = 0) or back (inverse = 1): with a 1x1
+ * conv C_in -> 4*C this is Deconvolution(kernel=2, stride=2). */
+int mxdet_pixel_shuffle2(const uint16_t* x, int64_t R, int32_t H, int32_t W, int32_t C, int32_t inverse,
+                         uint16_t* y, mxdet_stream_t stream);
+/* per-pixel sigmoid BCE on channel cls[r]-1 of logits [R,S,S,Cpad] (bf16), normalised by (#fg rois * S*S);
+ * grad (bf16, same shape) is fully written; loss_out[1] fp32, fixed-order reduction. */
+size_t mxdet_mask_loss_workspace_bytes(int64_t R, int32_t S);
+int mxdet_mask_loss(const uint16_t* logits, const int32_t* cls, const uint8_t* targets, int64_t R, int32_t S,
+                    int32_t Cpad, float loss_scale, float* loss_out, uint16_t* grad, void* workspace,
+                    size_t workspace_bytes, mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * backbones / necks / rpn_heads / bbox_heads / mask_heads (README.md:27-31) -- dense contractions.
  * MXNet roles: Convolution (+ BatchNorm(use_global_stats) + Activation + elemwise_add),
  * FullyConnected, Pooling, UpSampling. All bf16 in / fp32 accumulate on MFMA / bf16 out.

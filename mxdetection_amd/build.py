@@ -22,6 +22,7 @@ EXACT = ["-ffp-contract=off"]
 # MFMA conv / elementwise kernels: default contraction is fine (tolerance-checked).
 PER_FILE = {
     "conv.hip": [],
+    "mask.hip": ["-ffp-contract=off"],
     "wgrad.hip": [],
     "dense_misc.hip": [],
 }

@@ -1,0 +1,180 @@
+// mask.hip -- Mask R-CNN specific operators for gfx950: mask-target generation, 2x pixel shuffle (the data
+// movement half of the 2x2 stride-2 deconvolution) and the per-pixel sigmoid BCE mask loss.
+//
+// Slots: core/mask (/root/reference/README.md:18) and models/mask_heads (README.md:30); MXNet roles: the lineage's
+// mask-target CustomOp (numpy/cv2 crop + resize on the host), Deconvolution(kernel=2, stride=2) and a sigmoid BCE
+// on the ground-truth class channel (README.md:37). The deconvolution's arithmetic runs on the MFMA conv kernel as a
+// 1x1 convolution 256 -> 4*256 (one output group per (dy,dx)); this file only interleaves the four groups.
+#include "common.h"
+
+namespace mxdet {
+
+// ---- mask targets: crop the matched instance bitmask to the roi, resample to SxS, threshold at 0.5 -------------
+// target[r][py][px] = bilinear(mask_g, y = y1 + (py+0.5)*h/S - 0.5?, ...) >= 0.5 with the RoIAlign(aligned=False)
+// geometry: sample point = roi start + (p + 0.5) * bin, clamped bilinear taps, out-of-image samples = 0.
+__global__ void __launch_bounds__(256)
+mask_target_kernel(const float* __restrict__ rois, const int32_t* __restrict__ matched_gt,
+                   const int32_t* __restrict__ labels, const uint8_t* __restrict__ gt_masks, int R, int G_max,
+                   int H, int W, int S, uint8_t* __restrict__ targets, int32_t* __restrict__ cls_out) {
+  const int r = blockIdx.x;
+  const float* q = rois + (long long)r * 5;
+  const int n = (int)q[0];
+  const int g = matched_gt[r];
+  const int lab = labels[r];
+  const bool fg = lab > 0 && g >= 0 && g < G_max;
+  if (threadIdx.x == 0) cls_out[r] = fg ? lab : -1;
+  const float x1 = q[1], y1 = q[2];
+  float rw = q[3] - q[1], rh = q[4] - q[2];
+  rw = rw > 1.0f ? rw : 1.0f;
+  rh = rh > 1.0f ? rh : 1.0f;
+  const float bw = rw / (float)S, bh = rh / (float)S;
+  const uint8_t* m = gt_masks + ((long long)n * G_max + (fg ? g : 0)) * H * W;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    uint8_t t = 0;
+    if (fg) {
+      int py = i / S, px = i - py * S;
+      float y = y1 + ((float)py + 0.5f) * bh;
+      float x = x1 + ((float)px + 0.5f) * bw;
+      if (!(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W)) {
+        if (y <= 0.0f) y = 0.0f;
+        if (x <= 0.0f) x = 0.0f;
+        int yl = (int)y, xl = (int)x, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+        float ly = y - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+        float v = hy * hx * (float)m[(long long)yl * W + xl];
+        v = v + hy * lx * (float)m[(long long)yl * W + xh];
+        v = v + ly * hx * (float)m[(long long)yh * W + xl];
+        v = v + ly * lx * (float)m[(long long)yh * W + xh];
+        t = v >= 0.5f ? 1 : 0;
+      }
+    }
+    targets[(long long)r * S * S + i] = t;
+  }
+}
+
+// ---- pixel shuffle: x [R,H,W,4*C] with channel = (dy*2+dx)*C + c  ->  y [R,2H,2W,C]; and its inverse ------------
+__global__ void pixel_shuffle2_kernel(const uint4* __restrict__ x, int R, int H, int W, int C8, int inverse,
+                                      uint4* __restrict__ y) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)R * H * W * 4 * C8;
+  if (idx >= total) return;
+  int c8 = (int)(idx % C8);
+  long long t = idx / C8;
+  int d = (int)(t & 3);
+  t >>= 2;
+  int w = (int)(t % W);
+  t /= W;
+  int h = (int)(t % H);
+  int r = (int)(t / H);
+  long long packed = idx;   // [r][h][w][d][c8]
+  long long spread = ((((long long)r * 2 * H + (2 * h + (d >> 1))) * 2 * W) + (2 * w + (d & 1))) * C8 + c8;
+  if (inverse) y[packed] = x[spread]; else y[spread] = x[packed];
+}
+
+// ---- mask loss: sigmoid BCE on the ground-truth class channel, fused forward + backward -------------------------
+// logits bf16 [R,S,S,Cpad]; cls[r] in 1..num_classes (or -1: ignored roi); targets u8 [R,S,S].
+// grad (bf16, same shape) is written completely (zeros off the class channel). partial[blockIdx] = block loss sum.
+__global__ void __launch_bounds__(256)
+mask_loss_kernel(const uint16_t* __restrict__ logits, const int32_t* __restrict__ cls,
+                 const uint8_t* __restrict__ targets, int R, int SS, int Cpad, const int* __restrict__ num_fg_dev,
+                 float loss_scale, uint16_t* __restrict__ grad, float* __restrict__ partial) {
+  __shared__ float red[8];
+  const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)R * SS;
+  const int nfg = *num_fg_dev;   // number of foreground rois, counted on device
+  const float norm = 1.0f / (float)((nfg > 0 ? nfg : 1) * SS);
+  float l = 0.0f;
+  if (pix < total) {
+    const int r = (int)(pix / SS);
+    const int c = cls[r];
+    uint16_t* g = grad + pix * Cpad;
+    for (int k = 0; k < Cpad; k += 8) *(uint4*)(g + k) = make_uint4(0u, 0u, 0u, 0u);
+    if (c > 0 && c <= Cpad) {
+      float z = bf16_bits_to_f32(logits[pix * Cpad + (c - 1)]);
+      float t = (float)targets[pix];
+      float az = z < 0.0f ? -z : z;
+      float sp = mxdet_logf(1.0f + mxdet_expf(-az));
+      l = (z > 0.0f ? z : 0.0f) - z * t + sp;
+      float p = z >= 0.0f ? 1.0f / (1.0f + mxdet_expf(-z)) : mxdet_expf(z) / (1.0f + mxdet_expf(z));
+      g[c - 1] = f32_to_bf16_bits((p - t) * norm * loss_scale);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) l += __shfl_down(l, off);
+  int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wid] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * norm;
+}
+
+__global__ void count_pos_kernel(const int32_t* __restrict__ cls, int R, int* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool p = i < R && cls[i] > 0;
+  unsigned long long m = __ballot(p);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+__global__ void __launch_bounds__(256)
+mask_finalize_kernel(const float* __restrict__ partial, int count, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) acc += partial[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+}  // namespace mxdet
+
+using namespace mxdet;
+
+extern "C" int mxdet_mask_target(const float* rois, const int32_t* matched_gt, const int32_t* labels,
+                                 const uint8_t* gt_masks, int64_t R, int32_t G_max, int32_t H, int32_t W,
+                                 int32_t S, uint8_t* targets, int32_t* cls_out, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(R >= 0 && G_max > 0 && H > 0 && W > 0 && S > 0, MXDET_ESHAPE, "mask_target: bad shape");
+  if (R == 0) return MXDET_OK;
+  MXDET_REQUIRE(rois && matched_gt && labels && gt_masks && targets && cls_out, MXDET_EINVAL,
+                "mask_target: null pointer");
+  hipLaunchKernelGGL(mask_target_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), rois, matched_gt,
+                     labels, gt_masks, (int)R, G_max, H, W, S, targets, cls_out);
+  return check_launch("mask_target");
+}
+
+extern "C" int mxdet_pixel_shuffle2(const uint16_t* x, int64_t R, int32_t H, int32_t W, int32_t C,
+                                    int32_t inverse, uint16_t* y, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(R > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, MXDET_ESHAPE, "pixel_shuffle2: bad shape");
+  MXDET_REQUIRE(x && y, MXDET_EINVAL, "pixel_shuffle2: null pointer");
+  long long total = (long long)R * H * W * 4 * (C / 8);
+  hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3((unsigned)ceil_div<long long>(total, 256)), dim3(256), 0,
+                     as_stream(stream), (const uint4*)x, (int)R, H, W, C / 8, inverse, (uint4*)y);
+  return check_launch("pixel_shuffle2");
+}
+
+extern "C" size_t mxdet_mask_loss_workspace_bytes(int64_t R, int32_t S) {
+  long long blocks = ((long long)(R > 0 ? R : 0) * S * S + 255) / 256;
+  return (size_t)blocks * sizeof(float) + 256;
+}
+
+extern "C" int mxdet_mask_loss(const uint16_t* logits, const int32_t* cls, const uint8_t* targets, int64_t R,
+                               int32_t S, int32_t Cpad, float loss_scale, float* loss_out, uint16_t* grad,
+                               void* workspace, size_t workspace_bytes, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(R > 0 && S > 0 && Cpad > 0 && Cpad % 8 == 0, MXDET_ESHAPE, "mask_loss: bad shape");
+  MXDET_REQUIRE(logits && cls && targets && loss_out && grad, MXDET_EINVAL, "mask_loss: null pointer");
+  MXDET_REQUIRE(workspace && workspace_bytes >= mxdet_mask_loss_workspace_bytes(R, S), MXDET_EWORKSPACE,
+                "mask_loss: workspace too small");
+  hipStream_t s = as_stream(stream);
+  int* cnt = (int*)workspace;
+  float* partial = (float*)((char*)workspace + 256);
+  hipError_t e = hipMemsetAsync(cnt, 0, 256, s);
+  MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "mask_loss: memset failed");
+  hipLaunchKernelGGL(count_pos_kernel, dim3((unsigned)ceil_div<long long>(R, 256)), dim3(256), 0, s, cls, (int)R, cnt);
+  int blocks = (int)(((long long)R * S * S + 255) / 256);
+  hipLaunchKernelGGL(mask_loss_kernel, dim3(blocks), dim3(256), 0, s, logits, cls, targets, (int)R, S * S, Cpad,
+                     (const int*)cnt, loss_scale, grad, partial);
+  hipLaunchKernelGGL(mask_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, blocks, loss_out);
+  return check_launch("mask_loss");
+}

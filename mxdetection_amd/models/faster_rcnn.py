@@ -9,6 +9,7 @@ import torch
 
 from .backbones import ResNet
 from .bbox_heads import BBoxHead
+from .mask_heads import FCNMaskHead
 from .necks import FPN
 from .roi_extractors import FPNRoIExtractor
 from .rpn_heads import RPNHead
@@ -18,13 +19,20 @@ from .utils.layers import ParamArena, Workspace
 
 class FasterRCNN:
     def __init__(self, device="cuda", depth=50, num_classes=81, seed=7, rpn_seed=99, rois_per_image=512,
-                 pre_nms_top_n=2000, post_nms_top_n=2000):
+                 pre_nms_top_n=2000, post_nms_top_n=2000, with_mask=False):
         gen = torch.Generator().manual_seed(seed)
         self.device = device
         self.arena = ParamArena(device)
         self.ws = Workspace(device)
         self.strides = [4, 8, 16, 32, 64]
         # registration order == backward completion order (buckets become final early)
+        self.with_mask = with_mask
+        self.mask_head = None
+        if with_mask:   # Mask R-CNN (BASELINE.json config 4): the mask branch's backward runs first
+            self.mask_head = FCNMaskHead(256, self.arena, self.ws, device, gen, num_classes=num_classes,
+                                         rois_per_image=max(1, rois_per_image // 4))
+            self.mask_roi_extractor = FPNRoIExtractor([4, 8, 16, 32], pooled=(14, 14), device=device)
+        self.mark_mask = self.arena.size
         self.bbox_head = BBoxHead(7 * 7 * 256, self.arena, self.ws, device, gen, num_classes=num_classes,
                                   rois_per_image=rois_per_image, seed=rpn_seed)
         self.mark_head = self.arena.size
@@ -37,6 +45,8 @@ class FasterRCNN:
         self.roi_extractor = FPNRoIExtractor(self.strides[:4], device=device)
         self.arena.finalize()
         self.layers = self.bbox_head.layers() + self.rpn_head.layers() + self.neck.layers() + self.backbone.layers()
+        if with_mask:
+            self.layers = self.mask_head.layers() + self.layers
         for l in self.layers:
             l.materialize()
         self.arena.refresh_bf16()
@@ -97,6 +107,8 @@ class FasterRCNN:
         p_shapes.append((N, (p_shapes[-1][1] + 1) // 2, (p_shapes[-1][2] + 1) // 2, 256))
         self.rpn_head.plan(p_shapes, g_max)
         self.bbox_head.plan(N)
+        if self.with_mask:
+            self.mask_head.plan(N)
         self.ws.get()
         self.dP = [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in p_shapes]
         self.dC = [None] + [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in c_shapes[1:]]
@@ -122,14 +134,15 @@ class FasterRCNN:
         self.segments.append(self._cur_graph)
         self._cur_graph = None
 
-    def capture(self, image, gt_boxes, im_info, lr, image_offset=0, warmup=2):
+    def capture(self, image, gt_boxes, im_info, lr, image_offset=0, warmup=2, gt_masks=None):
         """Capture forward+backward+update into hipGraph segments (cut only at gradient all-reduces).
         The RNG step counter is read from device memory (step_dev), inputs from static buffers."""
         dev = self.device
         self.static_in = (image.clone(), gt_boxes.clone(), im_info.clone())
+        self.static_masks = gt_masks.clone() if gt_masks is not None else None
         self.step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         for i in range(warmup):     # eager warm-up: plans shapes and allocates every buffer
-            self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr)
+            self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr, gt_masks=self.static_masks)
         torch.cuda.synchronize()
         self._pool = torch.cuda.graph_pool_handle()
         self.segments = []
@@ -138,7 +151,8 @@ class FasterRCNN:
         with torch.cuda.stream(side):
             self._cap = True
             self._seg_begin()
-            losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev)
+            losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
+                                           gt_masks=self.static_masks)
             self.optimizer_step(lr)
             self._seg_end()
             self._cap = False
@@ -146,13 +160,15 @@ class FasterRCNN:
         torch.cuda.synchronize()
         self.static_losses = losses
 
-    def replay(self, image, gt_boxes, im_info, step):
+    def replay(self, image, gt_boxes, im_info, step, gt_masks=None):
         """One training step from the captured graphs."""
         si = self.static_in
         if image is not si[0]:
             si[0].copy_(image, non_blocking=True)
             si[1].copy_(gt_boxes, non_blocking=True)
             si[2].copy_(im_info, non_blocking=True)
+            if gt_masks is not None:
+                self.static_masks.copy_(gt_masks, non_blocking=True)
         self.step_dev.fill_(step)
         for seg in self.segments:
             if isinstance(seg, tuple):
@@ -164,7 +180,7 @@ class FasterRCNN:
                 seg.replay()
         return self.static_losses
 
-    def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0, step_dev=None):
+    def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0, step_dev=None, gt_masks=None):
         """image NCHW [N,3,H,W]; gt_boxes [N,G,5] f32 (class < 0 padding); im_info [N,3] f32."""
         N, _, H, W = image.shape
         self.plan(N, H, W, gt_boxes.shape[1])
@@ -177,10 +193,24 @@ class FasterRCNN:
         pooled = self.roi_extractor.forward(P, rois_s)
         self.bbox_head.forward(pooled)
         rcnn_loss = self.bbox_head.loss_and_grad()
+        mask_loss = None
+        if self.with_mask:
+            mrois = self.mask_head.select_rois(self.bbox_head)
+            self.mask_head.targets(gt_masks)
+            mpooled = self.mask_roi_extractor.forward(P, mrois)
+            self.mask_head.forward(mpooled)
+            mask_loss = self.mask_head.loss_and_grad()
         # ---- backward ----
+        if self.with_mask:
+            d_mpooled = self.mask_head.backward()
+            self._reduce(0, self.mark_mask)
         d_pooled = self.bbox_head.backward()
-        self._reduce(0, self.mark_head)
-        self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4])
+        self._reduce(self.mark_mask, self.mark_head)
+        if self.with_mask:
+            acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
+            self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=True)
+        else:
+            self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4])
         self.rpn_head.backward(self.dP, [True, True, True, True, False])
         self._reduce(self.mark_head, self.mark_rpn)
         self.neck.backward(self.dP, self.dC, [False, True, True, True])
@@ -190,6 +220,8 @@ class FasterRCNN:
             self._backbone_stage_backward(si)
             self._reduce(lo, self.stage_marks[si])
             lo = self.stage_marks[si]
+        if self.with_mask:
+            return rpn_loss, rcnn_loss, mask_loss
         return rpn_loss, rcnn_loss
 
     def _backbone_stage_backward(self, si):
@@ -216,7 +248,7 @@ class FasterRCNN:
         self.arena.sgd_step(lr, momentum, wd, rescale)
         self.refresh_transposed()
 
-    def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025):
-        losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset)
+    def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025, gt_masks=None):
+        losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset, gt_masks=gt_masks)
         self.optimizer_step(lr)
         return losses

@@ -1,1 +1,2 @@
-"""models/mask_heads (/root/reference/README.md:30) - Mask R-CNN head; BASELINE.json config 4 (next)."""
+"""models/mask_heads (/root/reference/README.md:30)."""
+from .fcn_mask_head import FCNMaskHead  # noqa: F401

@@ -26,12 +26,19 @@ class FPNRoIExtractor:
             self.out = torch.empty((R, self.pooled[0], self.pooled[1], C), dtype=torch.bfloat16, device=self.device)
         return roi_align_forward(self.feats, self.scales, rois, self.levels, self.pooled, self.sr, self.lvl_min, self.out)
 
-    def backward(self, grad_out, dP):
-        """Scatter grad_out into fp32 accumulators, then write them (rounded once) into the bf16 dP[l]."""
+    def backward(self, grad_out, dP, shared_acc=None, zero=True, finalize=True):
+        """Scatter grad_out into fp32 accumulators, then write them (rounded once) into the bf16 dP[l].
+        Several extractors (box + mask branch) may share one set of accumulators: the first zeroes, the last
+        finalizes."""
+        if shared_acc is not None:
+            self.dacc = shared_acc
         if self.dacc is None:
             self.dacc = [torch.empty(f.shape, dtype=torch.float32, device=self.device) for f in self.feats]
-        for a in self.dacc:
-            a.zero_()
+        if zero:
+            for a in self.dacc:
+                a.zero_()
         roi_align_backward(self.dacc, self.scales, self.rois, self.levels, grad_out, self.sr, self.lvl_min)
-        for a, d in zip(self.dacc, dP):
-            dense.f32_accum_to_bf16(a, d, accumulate=False)
+        if finalize:
+            for a, d in zip(self.dacc, dP):
+                dense.f32_accum_to_bf16(a, d, accumulate=False)
+        return self.dacc

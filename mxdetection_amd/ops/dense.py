@@ -139,6 +139,23 @@ def upsample2_backward(dfine, dcoarse, accumulate=False):
     return dcoarse
 
 
+def pixel_shuffle2(x, out=None, inverse=False):
+    """[R,H,W,4C] -> [R,2H,2W,C] (or back with inverse=True): the data movement of a 2x2 stride-2 deconvolution."""
+    lib = _lib.load()
+    if not inverse:
+        R, H, W, C4 = x.shape
+        Cc = C4 // 4
+        if out is None:
+            out = torch.empty((R, 2 * H, 2 * W, Cc), dtype=torch.bfloat16, device=x.device)
+    else:
+        R, H2, W2, Cc = x.shape
+        H, W = H2 // 2, W2 // 2
+        if out is None:
+            out = torch.empty((R, H, W, 4 * Cc), dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_pixel_shuffle2(ptr(x), R, H, W, Cc, int(inverse), ptr(out), stream_ptr()), "pixel_shuffle2")
+    return out
+
+
 def add_bf16(a, b, out=None):
     lib = _lib.load()
     if out is None:

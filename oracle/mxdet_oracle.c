@@ -718,6 +718,62 @@ API void oracle_maxpool3x3s2(const float* x, int N, int H, int W, int C, float* 
         }
 }
 
+/* ---- Mask R-CNN: mask targets and mask loss ------------------------------------------------------------- */
+API void oracle_mask_target(const float* rois, const int32_t* matched, const int32_t* labels,
+                            const uint8_t* masks, int64_t R, int G, int H, int W, int S, uint8_t* targets,
+                            int32_t* cls_out) {
+  for (int64_t r = 0; r < R; ++r) {
+    const float* q = rois + r * 5;
+    int n = (int)q[0], g = matched[r], lab = labels[r];
+    int fg = lab > 0 && g >= 0 && g < G;
+    cls_out[r] = fg ? lab : -1;
+    float rw = q[3] - q[1], rh = q[4] - q[2];
+    if (!(rw > 1.0f)) rw = 1.0f;
+    if (!(rh > 1.0f)) rh = 1.0f;
+    float bw = rw / (float)S, bh = rh / (float)S;
+    const uint8_t* m = masks + ((int64_t)n * G + (fg ? g : 0)) * H * W;
+    for (int py = 0; py < S; ++py)
+      for (int px = 0; px < S; ++px) {
+        uint8_t t = 0;
+        if (fg) {
+          float y = q[2] + ((float)py + 0.5f) * bh, x = q[1] + ((float)px + 0.5f) * bw;
+          int yl, yh, xl, xh, valid; float w[4];
+          o_taps(y, x, H, W, &yl, &yh, &xl, &xh, w, &valid);
+          if (valid) {
+            float v = w[0] * (float)m[(int64_t)yl * W + xl];
+            v = v + w[1] * (float)m[(int64_t)yl * W + xh];
+            v = v + w[2] * (float)m[(int64_t)yh * W + xl];
+            v = v + w[3] * (float)m[(int64_t)yh * W + xh];
+            t = v >= 0.5f ? 1 : 0;
+          }
+        }
+        targets[(r * S + py) * S + px] = t;
+      }
+  }
+}
+
+/* logits fp32 [R,S,S,Cpad]; returns loss (double) and grad fp32 (before bf16 rounding) */
+API void oracle_mask_loss(const float* logits, const int32_t* cls, const uint8_t* targets, int64_t R, int S,
+                          int Cpad, float loss_scale, float* grad, double* loss) {
+  int64_t nfg = 0;
+  for (int64_t r = 0; r < R; ++r) if (cls[r] > 0) ++nfg;
+  float norm = 1.0f / (float)((nfg > 0 ? nfg : 1) * S * S);
+  double acc = 0.0;
+  for (int64_t i = 0; i < R * S * S * Cpad; ++i) grad[i] = 0.0f;
+  for (int64_t r = 0; r < R; ++r) {
+    int c = cls[r];
+    if (!(c > 0 && c <= Cpad)) continue;
+    for (int i = 0; i < S * S; ++i) {
+      int64_t pix = r * S * S + i;
+      float z = logits[pix * Cpad + (c - 1)], t = (float)targets[pix];
+      float l = (z > 0 ? z : 0.0f) - z * t + o_softplus_neg_abs(z);
+      acc += (double)l;
+      grad[pix * Cpad + (c - 1)] = (o_sigmoid(z) - t) * norm * loss_scale;
+    }
+  }
+  loss[0] = acc * (double)norm;
+}
+
 /* expose the shared scalar helpers so tests can pin them against numpy float64 */
 API float oracle_expf(float x) { return mxdet_expf(x); }
 API float oracle_logf(float x) { return mxdet_logf(x); }

@@ -272,6 +272,28 @@ def focal_loss(logits, labels, alpha=0.25, gamma=2.0, grad_scale=1.0):
     return loss, grad
 
 
+def mask_target(rois, matched, labels, masks, S=28):
+    rois = _c(rois, np.float32).reshape(-1, 5)
+    masks = _c(masks, np.uint8)
+    N, G, H, W = masks.shape
+    R = rois.shape[0]
+    tg = np.zeros((R, S, S), np.uint8)
+    cls = np.zeros((R,), np.int32)
+    lib().oracle_mask_target(_vp(rois), _vp(_c(matched, np.int32)), _vp(_c(labels, np.int32)), _vp(masks), C.c_int64(R),
+                             C.c_int(G), C.c_int(H), C.c_int(W), C.c_int(S), _vp(tg), _vp(cls))
+    return tg, cls
+
+
+def mask_loss(logits, cls, targets, loss_scale=1.0):
+    logits = _c(logits, np.float32)
+    R, S, _, Cp = logits.shape
+    grad = np.zeros_like(logits)
+    loss = np.zeros(1, np.float64)
+    lib().oracle_mask_loss(_vp(logits), _vp(_c(cls, np.int32)), _vp(_c(targets, np.uint8)), C.c_int64(R), C.c_int(S),
+                           C.c_int(Cp), C.c_float(loss_scale), _vp(grad), _vp(loss))
+    return loss, grad
+
+
 # ---- dense ------------------------------------------------------------------------------------------
 def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False):
     x, w = _c(x, np.float32), _c(w, np.float32)
