@@ -138,7 +138,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda"
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MXDET_FORCE_DIST") == "1":   # the env knob exercises the RCCL path at world 1
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -149,7 +149,7 @@ def main():
     if not args.no_conv_timer:
         timer.install()
     model = FasterRCNN(device, depth=50, seed=7)
-    if world > 1:
+    if dist is not None:
         model.enable_data_parallel(world)
         dist.broadcast(model.arena.w, 0)
         model.arena.refresh_bf16()
