@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+constexpr int kWgradBKP = 32;   // pixels per step (32: 32 KiB of LDS -> 4+ workgroups per CU)
 struct WgradP {
   const uint16_t* x;   // [N,H,W,Cin]
   const uint16_t* dy;  // [N,Ho,Wo,Cout]
@@ -52,9 +53,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 2-stage LDS-DMA ring (global_load_lds_dwordx4, 1 KiB per wave instruction = 4 pixel rows x 256 B): the loads
 // of step t+1 are in flight while step t is multiplied; one s_waitcnt vmcnt(0) + one raw s_barrier per step.
 // The LDS image is lane-linear, so the granule swizzle is applied to the per-lane SOURCE chunk.
+template <int BKP>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(WgradP p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][64 * 256];  // [buf][dy|x]
+  constexpr int GI = BKP / 16;      // DMA instructions per wave per image per stage (4 pixel rows each)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][BKP * 256];  // [buf][dy|x]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -75,46 +78,61 @@ wgrad_kernel(WgradP p) {
   const int co0 = co_t * 128, ci0 = ci_t * 128;
 
   const int step0 = ks * p.steps_per_split;
-  int nsteps = ceil_div(p.M, 64) - step0;
+  int nsteps = ceil_div(p.M, BKP) - step0;
   nsteps = nsteps > p.steps_per_split ? p.steps_per_split : nsteps;
 
   // DMA geometry: wave w, instruction i (0..3) fills pixel rows 4*(4w+i) .. +3 of both images; lane l covers
   // row (l>>4), physical 16-B slot (l&15), i.e. logical chunk ((slot>>1) ^ f(row)) * 2 + (slot & 1)
   const int lrow = lane >> 4, lslot = lane & 15;
   const uint16_t* zero = (const uint16_t*)g_wgrad_zero;
+  // Each lane walks its GI pixel rows BKP pixels per step with an exact carry chain (BKP = d_img*HW + d_ho*Wo + d_wo,
+  // every component below its modulus), keeps 32-bit element offsets, and selects the zero page without branches.
   const int HW = p.Ho * p.Wo;
-  const int dq = 64 / p.Wo, dr = 64 - dq * p.Wo;     // 64 pixels = dq rows + dr columns
-  int c_img[4], c_ho[4], c_wo[4], c_m[4], c_chunk[4];
+  const int d_img = BKP / HW, d_rem = BKP - d_img * HW;
+  const int d_ho = d_rem / p.Wo, d_wo = d_rem - d_ho * p.Wo;
+  int c_img[GI], c_ho[GI], c_wo[GI], c_m[GI], c_offy[GI], c_chx[GI];
+  bool c_yok[GI], c_xok[GI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row = (wid * 4 + i) * 4 + lrow;
+  for (int i = 0; i < GI; ++i) {
+    int row = (wid * GI + i) * 4 + lrow;
     int f = (row & 3) | (((row >> 3) & 1) << 2);
-    c_chunk[i] = ((((lslot >> 1) ^ f) << 1) | (lslot & 1)) * 8;     // first channel of this lane's 16 bytes
-    int m = step0 * 64 + row;
+    int chunk = ((((lslot >> 1) ^ f) << 1) | (lslot & 1)) * 8;     // first channel of this lane's 16 bytes
+    int m = step0 * BKP + row;
     c_m[i] = m;
     c_img[i] = m / HW;
     int rem = m - c_img[i] * HW;
     c_ho[i] = rem / p.Wo;
     c_wo[i] = rem - c_ho[i] * p.Wo;
+    c_offy[i] = m * p.Cout + co0 + chunk;
+    c_chx[i] = ci0 + chunk;
+    c_yok[i] = (co0 + chunk) < p.Cout;
+    c_xok[i] = (ci0 + chunk) < p.Cin;
   }
+  const int stepy = BKP * p.Cout;
   auto issue_stage = [&](int buf, bool live) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < GI; ++i) {
       const bool mok = live && c_m[i] < p.M;
       const int hi = c_ho[i] * p.stride - p.pad + kh, wi = c_wo[i] * p.stride - p.pad + kw;
-      const bool yok = mok && (co0 + c_chunk[i]) < p.Cout;
-      const bool xok = mok && (ci0 + c_chunk[i]) < p.Cin && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
-      const uint16_t* py = yok ? p.dy + ((size_t)c_m[i] * p.Cout + co0 + c_chunk[i]) : zero;
-      const uint16_t* px = xok ? p.x + (((size_t)(c_img[i] * p.H + hi) * p.W + wi) * p.Cin + ci0 + c_chunk[i]) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(smem[buf][0] + (wid * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(smem[buf][1] + (wid * 4 + i) * 1024), 16, 0, 0);
-      // advance this row by 64 pixels
-      c_m[i] += 64;
-      c_wo[i] += dr;
-      c_ho[i] += dq;
-      if (c_wo[i] >= p.Wo) { c_wo[i] -= p.Wo; ++c_ho[i]; }
-      if (HW == 1) { c_img[i] += c_ho[i]; c_ho[i] = 0; }          // fully connected: one pixel per "image"
-      else if (c_ho[i] >= p.Ho) { int k = c_ho[i] / p.Ho; c_ho[i] -= k * p.Ho; c_img[i] += k; }
+      const bool yok = mok && c_yok[i];
+      const bool xok = mok && c_xok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const int offx = ((c_img[i] * p.H + hi) * p.W + wi) * p.Cin + c_chx[i];
+      const uint16_t* ay = p.dy + (unsigned)c_offy[i];
+      const uint16_t* ax = p.x + (unsigned)offx;
+      const uint16_t* py = yok ? ay : zero;
+      const uint16_t* px = xok ? ax : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(smem[buf][0] + (wid * GI + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(smem[buf][1] + (wid * GI + i) * 1024), 16, 0, 0);
+      // advance this row by BKP pixels
+      c_m[i] += BKP;
+      c_offy[i] += stepy;
+      c_wo[i] += d_wo;
+      int cw = c_wo[i] >= p.Wo ? 1 : 0;
+      c_wo[i] -= cw ? p.Wo : 0;
+      c_ho[i] += d_ho + cw;
+      int ch = c_ho[i] >= p.Ho ? 1 : 0;
+      c_ho[i] -= ch ? p.Ho : 0;
+      c_img[i] += d_img + ch;
     }
   };
 
@@ -138,7 +156,7 @@ wgrad_kernel(WgradP p) {
     const unsigned char* sy = smem[cur][0];
     const unsigned char* sx = smem[cur][1];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BKP / 32; ++kk) {
       const int rowa = kk * 32 + 8 * g + q;       // first 4 pixel rows of this lane group's k-range
       const int rowb = rowa + 4;
       const int fa = (rowa & 3) | (((rowa >> 3) & 1) << 2);
@@ -314,11 +332,12 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
   w.ci_tiles = ceil_div(d->Cin, 128);
   w.taps = d->KH * d->KW;
   long long M = (long long)d->N * d->Ho * d->Wo;
-  int steps = (int)ceil_div<long long>(M, 64);
+  int steps = (int)ceil_div<long long>(M, kWgradBKP);
   int tiles = w.co_tiles * w.ci_tiles * w.taps;
   // aim for ~4 workgroups per CU overall, at least 8 steps per split
   int want = ceil_div(1024, tiles);
-  int maxsplit = steps / 8 > 0 ? steps / 8 : 1;
+  const int min_steps = 512 / kWgradBKP;   // at least 512 pixels per split
+  int maxsplit = steps / min_steps > 0 ? steps / min_steps : 1;
   int ks = want < maxsplit ? want : maxsplit;
   ks = ks < 1 ? 1 : (ks > 64 ? 64 : ks);
   w.steps_per_split = ceil_div(steps, ks);
@@ -373,7 +392,7 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
   p.co_tiles = w.co_tiles; p.ci_tiles = w.ci_tiles; p.ksplit = w.ksplit;
   p.steps_per_split = w.steps_per_split;
   long long nwg = (long long)w.co_tiles * w.ci_tiles * w.taps * w.ksplit;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(wgrad_kernel<kWgradBKP>, dim3((unsigned)nwg), dim3(256), 0, s, p);
   long long params = (long long)d->Cout * w.taps * d->Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div<long long>(params / 4, 256)), dim3(256),
                      0, s, (const float*)workspace, w.ksplit, params, d->accumulate, dw);
