@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the main stream")
     args = ap.parse_args()
 
     import torch
@@ -149,6 +150,8 @@ def main():
     if not args.no_conv_timer:
         timer.install()
     model = FasterRCNN(device, depth=50, seed=7)
+    if not args.no_wgrad_stream:
+        model.enable_wgrad_stream()
     if dist is not None:
         model.enable_data_parallel(world)
         dist.broadcast(model.arena.w, 0)
@@ -227,6 +230,7 @@ def main():
                        "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
                        "frozen": "stem+C2, frozen BN folded", "optimizer": "SGD momentum 0.9 wd 1e-4",
                        "launch": "hipGraph replay" if use_graph else "eager",
+                       "wgrad_side_stream": not args.no_wgrad_stream,
                        "params_trainable": model.num_params()},
             "model_mfma_roofline_frac": round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4),
             "losses_last_step": {"rpn_cls": loss_vals[0], "rpn_reg": loss_vals[1], "rcnn_cls": loss_vals[2],

@@ -90,6 +90,10 @@ class FasterRCNN:
             self._tr_table = dense.make_transpose_table(pairs, self.device)
         dense.filter_transpose_batched(*self._tr_table)
 
+    def enable_wgrad_stream(self):
+        """Issue weight-gradient kernels on a second stream (overlaps them with the data-gradient chain)."""
+        self.ws.side = torch.cuda.Stream()
+
     def enable_data_parallel(self, world_size):
         import torch.distributed as dist
         self.dist = dist
@@ -116,6 +120,7 @@ class FasterRCNN:
 
     # ---- gradient buckets -----------------------------------------------------------------------
     def _reduce(self, lo, hi):
+        self.ws.join()            # the bucket's weight gradients were produced on the side stream
         if self._cap:
             if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
                 self._seg_end()
@@ -237,6 +242,7 @@ class FasterRCNN:
                 b.backward(ds, None, False)
 
     def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
+        self.ws.join()
         if self._cap:
             if self.dist is not None:
                 self._seg_end()

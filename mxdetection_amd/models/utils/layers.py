@@ -18,12 +18,27 @@ from ...ops import dense
 
 
 class Workspace:
-    """One caller-owned scratch buffer shared by every wgrad call (the C-ABI never allocates)."""
+    """One caller-owned scratch buffer shared by every wgrad call (the C-ABI never allocates).
+
+    `side` (optional HIP stream): weight-gradient kernels only feed the optimizer, so they are issued on a second
+    stream that forks from the main stream at each call (after the producer of dy) and is joined before the
+    gradient exchange / optimizer. They then overlap the dgrad chain instead of sitting on its critical path."""
 
     def __init__(self, device):
         self.device = device
         self.need = 0
         self.buf = None
+        self.side = None
+
+    def fork(self):
+        if self.side is None:
+            return None
+        self.side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def require(self, nbytes):
         self.need = max(self.need, int(nbytes))
@@ -135,4 +150,9 @@ class ConvLayer:
     def backward_weight(self, x, dy, accumulate=False):
         dw = self.arena.view(self.wi, "g")
         db = self.arena.view(self.bi, "g") if self.train_bias else None
-        dense.conv2d_wgrad(x, dy, self.k, self.k, self.stride, self.pad, dw, db, accumulate, self.ws.get())
+        ctx = self.ws.fork()
+        if ctx is None:
+            dense.conv2d_wgrad(x, dy, self.k, self.k, self.stride, self.pad, dw, db, accumulate, self.ws.get())
+        else:
+            with ctx:
+                dense.conv2d_wgrad(x, dy, self.k, self.k, self.stride, self.pad, dw, db, accumulate, self.ws.get())
