@@ -59,6 +59,7 @@ class ConvTimer:
         self.log = []
         self.logging = False
         self.orig = {}
+        self.heaviest = {}    # family -> (flops, seconds) of its largest launch
 
     def install(self):
         from mxdetection_amd.ops import dense
@@ -108,6 +109,8 @@ class ConvTimer:
             acc[0] += flops
             acc[1] += t
             acc[2] += 1
+            if family not in self.heaviest or flops > self.heaviest[family][0]:
+                self.heaviest[family] = (flops, t)
         return fam
 
 
@@ -221,6 +224,20 @@ def main():
                         "unit": "TFLOP/s", "frac": round(fl / tt / MFMA_PEAK_BF16, 4), "traffic": None,
                         "launches_per_step": n, "avg_launch_ms": round(1e3 * tt / n, 4),
                         "method": "each conv launch of one step re-issued 4x back-to-back between HIP events"}
+        # heaviest single launch of the dominant family (the P2-level 3x3 layer), with the HBM traffic measured for
+        # exactly that launch in separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
+        if roofline is not None and timer.heaviest.get(roofline["kernel"]):
+            hfl, ht = timer.heaviest[roofline["kernel"]]
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = json.load(f).get(roofline["kernel"], {}).get("hbm_bytes")
+            except Exception:  # noqa: BLE001
+                traffic = None
+            roofline["heaviest_launch"] = {"shape": "N=2 200x336 256->256 3x3", "gflop": round(hfl / 1e9, 1),
+                                           "ms": round(1e3 * ht, 4), "achieved": round(hfl / ht / 1e12, 1),
+                                           "frac": round(hfl / ht / MFMA_PEAK_BF16, 4), "traffic_bytes": traffic}
+            roofline["traffic"] = traffic
         out = {
             "metric": "images/sec (whole node) Faster R-CNN R50-FPN 3x800x1333",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
