@@ -180,6 +180,22 @@ int mxdet_focal_loss(const void* logits, int32_t dtype, const int32_t* labels, i
                      float alpha, float gamma, float grad_scale, float* loss_out, void* grad_logits,
                      void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
 
+/* RetinaNet: per-anchor class labels (class of the matched GT for label == 1, else the -1 / 0 label) and the
+ * number of foreground anchors (device word, the loss normaliser). */
+int mxdet_anchor_class_labels(const int32_t* labels, const int32_t* matched_gt, const float* gt_boxes, int32_t N,
+                              int64_t A_total, int32_t G_max, int32_t* cls_labels, int32_t* num_fg,
+                              mxdet_stream_t stream);
+/* RetinaNet losses fused fwd+bwd over one pyramid level: sigmoid focal loss on cls[cell*ld_cls + a*C + c] and
+ * smooth-L1 on reg[cell*ld_reg + a*4 + k] (bf16 channels-last head outputs), both normalised by max(1, *num_fg);
+ * gradients written in place of the same layout (padding channels untouched); partial sums (cls, reg) per
+ * workgroup, reduced by mxdet_loss_finalize. */
+int32_t mxdet_retina_loss_num_partials(int32_t N, int32_t H, int32_t W, int32_t A);
+int mxdet_retina_loss_level(const uint16_t* cls, const uint16_t* reg, int32_t N, int32_t H, int32_t W, int32_t A,
+                            int32_t C, int32_t ld_cls, int32_t ld_reg, const int32_t* cls_labels,
+                            const float* bbox_targets, int64_t A_total, int64_t level_offset, float alpha,
+                            float gamma, float sigma, const int32_t* num_fg, float loss_scale, uint16_t* grad_cls,
+                            uint16_t* grad_reg, float* partial, mxdet_stream_t stream);
+
 /* RPN losses fused fwd+bwd over one pyramid level's head output.
  * head: bf16 [N,H,W,Cpad] channels-last, channel a = objectness logit of anchor a, channel
  * A + 4a + k = delta k of anchor a. labels / bbox_targets are the mxdet_anchor_target outputs

@@ -72,6 +72,10 @@ SIGNATURES = {
     "mxdet_loss_workspace_bytes": (c_sz, [c_i64]),
     "mxdet_focal_loss": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz,
                                  c_vp]),
+    "mxdet_anchor_class_labels": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "mxdet_retina_loss_num_partials": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    "mxdet_retina_loss_level": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64,
+                                        c_i64, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_rpn_loss_num_partials": (c_i32, [c_i32, c_i32, c_i32]),
     "mxdet_rpn_loss_level": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_i64, c_f32,
                                      c_f32, c_f32, c_vp, c_vp, c_vp]),

@@ -68,3 +68,25 @@ def rcnn_loss(cls_logits, bbox_pred, labels, bbox_targets, bbox_weights, num_cla
                               ptr(bbox_targets), ptr(bbox_weights), R, num_classes, reg_dim, sigma, norm, loss_scale,
                               ptr(loss_out), ptr(grad_cls), ptr(grad_reg), ptr(workspace), workspace.numel(),
                               stream_ptr()), "rcnn_loss")
+
+
+def anchor_class_labels(labels, matched_gt, gt_boxes, cls_labels, num_fg):
+    """RetinaNet: labels/matched [N,A] i32 -> cls_labels [N,A] (class id for fg), num_fg i32[1]."""
+    lib = _lib.load()
+    N, A = labels.shape
+    check(lib.mxdet_anchor_class_labels(ptr(labels), ptr(matched_gt), ptr(gt_boxes), N, A, gt_boxes.shape[1],
+                                        ptr(cls_labels), ptr(num_fg), stream_ptr()), "anchor_class_labels")
+
+
+def retina_loss_num_partials(N, H, W, A):
+    return _lib.load().mxdet_retina_loss_num_partials(N, H, W, A)
+
+
+def retina_loss_level(cls, reg, A, C, cls_labels, bbox_targets, level_offset, alpha, gamma, sigma, num_fg, loss_scale,
+                      grad_cls, grad_reg, partial):
+    lib = _lib.load()
+    N, H, W, ld_cls = cls.shape
+    check(lib.mxdet_retina_loss_level(ptr(cls), ptr(reg), N, H, W, A, C, ld_cls, reg.shape[3], ptr(cls_labels),
+                                      ptr(bbox_targets), cls_labels.shape[1], level_offset, alpha, gamma, sigma,
+                                      ptr(num_fg), loss_scale, ptr(grad_cls), ptr(grad_reg), ptr(partial), stream_ptr()),
+          "retina_loss_level")

@@ -345,3 +345,135 @@ extern "C" int mxdet_rcnn_loss(const void* cls_logits, const void* bbox_pred, in
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, partial, (int)R, 2, loss_out);
   return check_launch("rcnn_loss");
 }
+
+// ------------------------------------------------------------------------------------------------
+// RetinaNet (BASELINE.json config 5): dense-anchor class labels and the fused focal + box loss of one level.
+namespace mxdet {
+
+// cls_label = class of the matched GT for foreground anchors, else the {-1, 0} label itself
+__global__ void anchor_class_labels_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ matched,
+                                           const float* __restrict__ gt, long long A_total, int G_max, long long total,
+                                           int32_t* __restrict__ cls_labels, int* __restrict__ num_fg) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int lab = -1;
+  bool fg = false;
+  if (i < total) {
+    lab = labels[i];
+    if (lab == 1) {
+      int n = (int)(i / A_total);
+      lab = (int)gt[((long long)n * G_max + matched[i]) * 5 + 4];
+      fg = true;
+    }
+    cls_labels[i] = lab;
+  }
+  unsigned long long m = __ballot(fg);
+  if (lane_id() == 0 && m) atomicAdd(num_fg, __popcll(m));
+}
+
+// one thread per (cell, anchor): C contiguous class logits at cls[cell*ld_cls + a*C], 4 deltas at reg[cell*ld_reg + a*4]
+__global__ void __launch_bounds__(256)
+retina_loss_kernel(const uint16_t* __restrict__ cls, const uint16_t* __restrict__ reg, int N, int HW, int A, int C,
+                   int ld_cls, int ld_reg, const int32_t* __restrict__ cls_labels, const float4* __restrict__ targets,
+                   long long A_total, long long level_offset, float alpha, float gamma, float sigma2,
+                   const int* __restrict__ num_fg, float loss_scale, uint16_t* __restrict__ gcls,
+                   uint16_t* __restrict__ greg, float* __restrict__ partial) {
+  __shared__ float red[8];
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * HW * A;
+  const int nf = *num_fg;
+  const float inv = 1.0f / (float)(nf > 1 ? nf : 1);
+  float lc = 0.0f, lr = 0.0f;
+  if (idx < total) {
+    const int a = (int)(idx % A);
+    const long long cell = idx / A;                 // n*HW + local cell
+    const int n = (int)(cell / HW);
+    const long long local = cell - (long long)n * HW;
+    const long long gi = (long long)n * A_total + level_offset + local * A + a;
+    const int lab = cls_labels[gi];
+    const uint16_t* z = cls + cell * ld_cls + (long long)a * C;
+    uint16_t* gz = gcls + cell * ld_cls + (long long)a * C;
+    for (int c = 0; c < C; ++c) {
+      float g = 0.0f;
+      if (lab >= 0) {
+        float x = bf16_bits_to_f32(z[c]);
+        float p = sigmoidf_det(x);
+        float sp = softplus_neg_abs(x);
+        float logp = -((x < 0.0f ? -x : 0.0f) + sp);
+        float log1mp = -((x > 0.0f ? x : 0.0f) + sp);
+        if (lab == c + 1) {
+          float q = 1.0f - p;
+          float mod = (gamma == 2.0f) ? q * q : mxdet_expf(gamma * mxdet_logf(q > 1e-30f ? q : 1e-30f));
+          lc += -alpha * mod * logp;
+          g = -alpha * mod * (q - gamma * p * logp);
+        } else {
+          float mod = (gamma == 2.0f) ? p * p : mxdet_expf(gamma * mxdet_logf(p > 1e-30f ? p : 1e-30f));
+          lc += -(1.0f - alpha) * mod * log1mp;
+          g = (1.0f - alpha) * mod * (p - gamma * (1.0f - p) * log1mp);
+        }
+      }
+      gz[c] = f32_to_bf16_bits(g * inv * loss_scale);
+    }
+    const uint16_t* d = reg + cell * ld_reg + a * 4;
+    uint16_t* gd = greg + cell * ld_reg + a * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lab > 0) t = targets[gi];
+    const float tt[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float g = 0.0f;
+      if (lab > 0) {
+        float e = bf16_bits_to_f32(d[k]) - tt[k];
+        lr += mxdet_smooth_l1(e, sigma2);
+        g = mxdet_smooth_l1_grad(e, sigma2) * inv * loss_scale;
+      }
+      gd[k] = f32_to_bf16_bits(g);
+    }
+  }
+  float s0 = block_sum_fixed(lc, red);
+  float s1 = block_sum_fixed(lr, red);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x + 0] = s0 * inv;
+    partial[2 * blockIdx.x + 1] = s1 * inv;
+  }
+}
+
+}  // namespace mxdet
+
+extern "C" int mxdet_anchor_class_labels(const int32_t* labels, const int32_t* matched_gt, const float* gt_boxes,
+                                         int32_t N, int64_t A_total, int32_t G_max, int32_t* cls_labels,
+                                         int32_t* num_fg, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(N > 0 && A_total > 0 && G_max > 0, MXDET_ESHAPE, "anchor_class_labels: bad shape");
+  MXDET_REQUIRE(labels && matched_gt && gt_boxes && cls_labels && num_fg, MXDET_EINVAL, "anchor_class_labels: null pointer");
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(num_fg, 0, sizeof(int32_t), s);
+  MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "anchor_class_labels: memset failed");
+  long long total = (long long)N * A_total;
+  hipLaunchKernelGGL(anchor_class_labels_kernel, dim3((unsigned)ceil_div<long long>(total, 256)), dim3(256), 0, s, labels,
+                     matched_gt, gt_boxes, (long long)A_total, G_max, total, cls_labels, num_fg);
+  return check_launch("anchor_class_labels");
+}
+
+extern "C" int32_t mxdet_retina_loss_num_partials(int32_t N, int32_t H, int32_t W, int32_t A) {
+  return (int32_t)(((long long)N * H * W * A + 255) / 256);
+}
+
+extern "C" int mxdet_retina_loss_level(const uint16_t* cls, const uint16_t* reg, int32_t N, int32_t H, int32_t W,
+                                       int32_t A, int32_t C, int32_t ld_cls, int32_t ld_reg,
+                                       const int32_t* cls_labels, const float* bbox_targets, int64_t A_total,
+                                       int64_t level_offset, float alpha, float gamma, float sigma,
+                                       const int32_t* num_fg, float loss_scale, uint16_t* grad_cls,
+                                       uint16_t* grad_reg, float* partial, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(N > 0 && H > 0 && W > 0 && A > 0 && C > 0 && ld_cls >= A * C && ld_reg >= 4 * A, MXDET_ESHAPE,
+                "retina_loss_level: bad shape");
+  MXDET_REQUIRE(cls && reg && cls_labels && bbox_targets && num_fg && grad_cls && grad_reg && partial, MXDET_EINVAL,
+                "retina_loss_level: null pointer");
+  MXDET_REQUIRE(level_offset >= 0 && level_offset + (int64_t)H * W * A <= A_total, MXDET_ESHAPE,
+                "retina_loss_level: level outside the anchor range");
+  int blocks = mxdet_retina_loss_num_partials(N, H, W, A);
+  hipLaunchKernelGGL(retina_loss_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), cls, reg, N, H * W, A, C, ld_cls,
+                     ld_reg, cls_labels, (const float4*)bbox_targets, (long long)A_total, (long long)level_offset, alpha,
+                     gamma, sigma * sigma, (const int*)num_fg, loss_scale, grad_cls, grad_reg, partial);
+  return check_launch("retina_loss_level");
+}

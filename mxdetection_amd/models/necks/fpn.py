@@ -76,3 +76,76 @@ class FPN:
                 top = i == L - 1
                 self.lats[i].backward_data(dinner[i], self.feats[i].shape, relu_mask=self.feats[i] if top else None,
                                            out=dC[i])
+
+
+class RetinaFPN:
+    """RetinaNet pyramid P3..P7: laterals + top-down on C3..C5, P6 = 3x3/2 conv on C5, P7 = 3x3/2 conv on ReLU(P6)
+    (RetinaNet variant)."""
+
+    def __init__(self, in_channels, out_channels, arena, ws, device, gen):
+        kw = dict(arena=arena, ws=ws, device=device, gen=gen)
+        L = len(in_channels)   # C3, C4, C5
+        xav = lambda cin, k: (1.0 / (k * k * cin)) ** 0.5   # noqa: E731
+        self.p7 = ConvLayer("fpn.p7", out_channels, out_channels, 3, 2, init_std=xav(out_channels, 3), **kw)
+        self.outs = [ConvLayer("fpn.out%d" % (i + 3), out_channels, out_channels, 3, init_std=xav(out_channels, 3), **kw)
+                     for i in range(L)]
+        self.p6 = ConvLayer("fpn.p6", in_channels[-1], out_channels, 3, 2, init_std=xav(in_channels[-1], 3), **kw)
+        self.lats = [ConvLayer("fpn.lat%d" % (i + 3), in_channels[i], out_channels, 1, init_std=xav(in_channels[i], 1), **kw)
+                     for i in range(L)]
+        self.L, self.C, self.device = L, out_channels, device
+        self.bufs = {}
+
+    def layers(self):
+        return [self.p7] + self.outs + [self.p6] + self.lats
+
+    def _buf(self, key, shape):
+        b = self.bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+            self.bufs[key] = b
+        return b
+
+    def plan(self, c_shapes):
+        for i, s in enumerate(c_shapes):
+            self.lats[i].plan(s)
+            self.outs[i].plan((s[0], s[1], s[2], self.C))
+        self.p6.plan(c_shapes[-1])
+        self.p7.plan(self.p6.out_shape(c_shapes[-1]))
+        s6 = self.p6.out_shape(c_shapes[-1])
+        return [(s[0], s[1], s[2], self.C) for s in c_shapes] + [s6, self.p7.out_shape(s6)]
+
+    def forward(self, feats):
+        L = self.L
+        self.feats = feats
+        inner = [None] * L
+        for i in reversed(range(L)):
+            res = inner[i + 1] if i + 1 < L else None
+            inner[i] = self.lats[i].forward(feats[i], residual=res, res_upsample=res is not None,
+                                            out=self._buf("inner%d" % i, feats[i].shape[:3] + (self.C,)))
+        P = [self.outs[i].forward(inner[i], out=self._buf("P%d" % i, inner[i].shape)) for i in range(L)]
+        self.p6_raw = self.p6.forward(feats[-1], out=self._buf("P6", self.p6.out_shape(feats[-1].shape)))
+        self.p6_relu = dense.relu_forward(self.p6_raw, self._buf("P6r", self.p6_raw.shape))
+        p7 = self.p7.forward(self.p6_relu, out=self._buf("P7", self.p7.out_shape(self.p6_relu.shape)))
+        self.inner, self.P = inner, P + [self.p6_raw, p7]
+        return self.P
+
+    def backward(self, dP, dC):
+        """dP[0..4] = gradients w.r.t. P3..P7; dC[0..2] receive gradients w.r.t. C3..C5 (C5 masked by C5 > 0)."""
+        L = self.L
+        # P7 = conv(ReLU(P6)): d(P6) = dP6 (heads) + (P6 > 0) * dgrad_p7(dP7)
+        self.p7.backward_weight(self.p6_relu, dP[L + 1])
+        t = self.p7.backward_data(dP[L + 1], self.p6_relu.shape, relu_mask=self.p6_relu, out=self._buf("dP6r", self.p6_relu.shape))
+        dense.add_bf16(dP[L], t, dP[L])
+        dinner = [None] * L
+        for i in range(L):
+            self.outs[i].backward_weight(self.inner[i], dP[i])
+            dinner[i] = self.outs[i].backward_data(dP[i], self.inner[i].shape, out=self._buf("dinner%d" % i, self.inner[i].shape))
+            if i > 0:
+                dense.upsample2_backward(dinner[i - 1], dinner[i], accumulate=True)
+        self.p6.backward_weight(self.feats[-1], dP[L])
+        self.p6.backward_data(dP[L], self.feats[-1].shape, out=dC[L - 1])
+        for i in range(L):
+            self.lats[i].backward_weight(self.feats[i], dinner[i])
+            top = i == L - 1
+            self.lats[i].backward_data(dinner[i], self.feats[i].shape, residual=dC[i] if top else None,
+                                       relu_mask=self.feats[i] if top else None, out=dC[i])

@@ -1,0 +1,152 @@
+"""Shared training-step machinery of the detectors: parameter arena bookkeeping, bucketed gradient exchange, hipGraph
+capture / replay of the whole step, side-stream weight gradients, optimizer step."""
+import torch
+
+from .dp import BucketReducer
+from .layers import ParamArena, Workspace
+
+
+class DetectorBase:
+    def _init_base(self, device):
+        self.device = device
+        self.arena = ParamArena(device)
+        self.ws = Workspace(device)
+        self.planned = None
+        self.dist = None
+        self.world = 1
+        self.segments = None
+        self._cap = False
+        self._cur_graph = None
+        self._tr_table = None
+        self.static_extra = {}
+
+    def _finalize_params(self, layers, frozen_layers=()):
+        self.layers = layers
+        self.frozen_layers = list(frozen_layers)
+        self.arena.finalize()
+        for l in self.layers:
+            l.materialize()
+        self.arena.refresh_bf16()
+        self.refresh_transposed()
+        self.reducer = BucketReducer(self.arena.g, None)
+
+    def export_params(self):
+        """name -> fp32 CPU tensor of every parameter as the kernels see it (bf16 filters, fp32 biases)."""
+        out = {"stem.weight": self.backbone.stem_w.float().cpu(), "stem.bias": self.backbone.stem_b.float().cpu()}
+        frozen = [l for st in self.backbone.stages for b in st for l in b.layers() if not l.trainable]
+        for l in self.layers + frozen:
+            out[l.name + ".weight"] = l.w_bf16.float().cpu()
+            if l.has_bias:
+                out[l.name + ".bias"] = l.bias_f32.float().cpu()
+        return out
+
+    def export_grads(self):
+        """name -> fp32 CPU gradient of every trainable parameter."""
+        return {e[0]: self.arena.view(i, "g").float().cpu() for i, e in enumerate(self.arena.entries)}
+
+    def num_params(self):
+        return sum(e[3] for e in self.arena.entries)
+
+    def refresh_transposed(self):
+        """[Cout,KH,KW,Cin] -> [Cin,KH,KW,Cout] copies for dgrad: one batched launch for all trainable filters."""
+        from ..ops import dense
+        if getattr(self, "_tr_table", None) is None:
+            pairs = [(l.w_bf16, l.wt) for l in self.layers if l.trainable]
+            self._tr_table = dense.make_transpose_table(pairs, self.device)
+        dense.filter_transpose_batched(*self._tr_table)
+
+    def enable_wgrad_stream(self):
+        """Issue weight-gradient kernels on a second stream (overlaps them with the data-gradient chain)."""
+        self.ws.side = torch.cuda.Stream()
+
+    def enable_data_parallel(self, world_size):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = world_size
+        self.reducer = BucketReducer(self.arena.g, dist)
+
+    def _reduce(self, lo, hi):
+        self.ws.join()            # the bucket's weight gradients were produced on the side stream
+        if self._cap:
+            if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
+                self._seg_end()
+                self.segments.append(("reduce", lo, hi))
+                self._seg_begin()
+            return
+        self.reducer.reduce(lo, hi)
+
+    # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
+
+    def _seg_begin(self):
+        self._cur_graph = torch.cuda.CUDAGraph()
+        self._cur_graph.capture_begin(pool=self._pool)
+
+    def _seg_end(self):
+        self._cur_graph.capture_end()
+        self.segments.append(self._cur_graph)
+        self._cur_graph = None
+
+    # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
+    def capture(self, image, gt_boxes, im_info, lr, image_offset=0, warmup=2, gt_masks=None):
+        """Capture forward+backward+update into hipGraph segments (cut only at gradient all-reduces).
+        The RNG step counter is read from device memory (step_dev), inputs from static buffers."""
+        dev = self.device
+        self.static_in = (image.clone(), gt_boxes.clone(), im_info.clone())
+        self.static_masks = gt_masks.clone() if gt_masks is not None else None
+        self.step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        for i in range(warmup):     # eager warm-up: plans shapes and allocates every buffer
+            self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr, gt_masks=self.static_masks)
+        torch.cuda.synchronize()
+        self._pool = torch.cuda.graph_pool_handle()
+        self.segments = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._cap = True
+            self._seg_begin()
+            losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
+                                           gt_masks=self.static_masks)
+            self.optimizer_step(lr)
+            self._seg_end()
+            self._cap = False
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.static_losses = losses
+
+    def replay(self, image, gt_boxes, im_info, step, gt_masks=None):
+        """One training step from the captured graphs."""
+        si = self.static_in
+        if image is not si[0]:
+            si[0].copy_(image, non_blocking=True)
+            si[1].copy_(gt_boxes, non_blocking=True)
+            si[2].copy_(im_info, non_blocking=True)
+            if gt_masks is not None:
+                self.static_masks.copy_(gt_masks, non_blocking=True)
+        self.step_dev.fill_(step)
+        for seg in self.segments:
+            if isinstance(seg, tuple):
+                if seg[0] == "reduce":
+                    self.reducer.reduce(seg[1], seg[2])
+                else:
+                    self.reducer.wait()
+            else:
+                seg.replay()
+        return self.static_losses
+
+    def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
+        self.ws.join()
+        if self._cap:
+            if self.dist is not None:
+                self._seg_end()
+                self.segments.append(("wait",))
+                self._seg_begin()
+        else:
+            self.reducer.wait()
+        rescale = 1.0 / self.world
+        self.arena.sgd_step(lr, momentum, wd, rescale)
+        self.refresh_transposed()
+
+    def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025, gt_masks=None):
+        losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset, gt_masks=gt_masks)
+        self.optimizer_step(lr)
+        return losses

@@ -172,6 +172,11 @@ def relu_backward(dy, y, out=None):
     return out
 
 
+def relu_forward(x, out=None):
+    """y = max(x, 0) (bf16): the ReLU-backward kernel with dy = y = x passes x where x > 0."""
+    return relu_backward(x, x, out)
+
+
 def f32_to_bf16(x, out=None):
     lib = _lib.load()
     if out is None:
