@@ -49,7 +49,7 @@ class DetectorBase:
 
     def refresh_transposed(self):
         """[Cout,KH,KW,Cin] -> [Cin,KH,KW,Cout] copies for dgrad: one batched launch for all trainable filters."""
-        from ..ops import dense
+        from ...ops import dense
         if getattr(self, "_tr_table", None) is None:
             pairs = [(l.w_bf16, l.wt) for l in self.layers if l.trainable]
             self._tr_table = dense.make_transpose_table(pairs, self.device)
