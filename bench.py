@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--no-conv-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the main stream")
+    ap.add_argument("--model", default="faster_rcnn", choices=["faster_rcnn", "mask_rcnn", "retinanet"],
+                    help="faster_rcnn = BASELINE.json headline (configs 1-3); mask_rcnn = config 4; retinanet = config 5 (R101)")
     args = ap.parse_args()
 
     import torch
@@ -148,11 +150,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
-    from mxdetection_amd.models import FasterRCNN
+    from mxdetection_amd.models import FasterRCNN, RetinaNet
     timer = ConvTimer()
     if not args.no_conv_timer:
         timer.install()
-    model = FasterRCNN(device, depth=50, seed=7)
+    if args.model == "retinanet":
+        model = RetinaNet(device, depth=101, seed=7)
+    else:
+        model = FasterRCNN(device, depth=50, seed=7, with_mask=(args.model == "mask_rcnn"))
     if not args.no_wgrad_stream:
         model.enable_wgrad_stream()
     if dist is not None:
@@ -163,16 +168,29 @@ def main():
     # linear-scaling rule from lr 0.02 @ batch 16, at the warm-up start factor 1/3 (random-init weights, no BN)
     lr = 0.02 * (BATCH_PER_GPU * world) / 16.0 / 3.0
     batches = [synth_batch(rank, s, device) for s in range(4)]
+    masks = None
+    if args.model == "mask_rcnn":   # filled ellipse inside every GT box, [N,16,H,W] u8 (GT rows 0..15 are the valid ones)
+        masks = []
+        yy = torch.arange(IM_H, device=device).view(1, 1, IM_H, 1).float()
+        xx = torch.arange(PAD_W, device=device).view(1, 1, 1, PAD_W).float()
+        for (_, gt, _) in batches:
+            b = gt[:, :16]
+            cx, cy = 0.5 * (b[..., 0] + b[..., 2]), 0.5 * (b[..., 1] + b[..., 3])
+            rx, ry = 0.5 * (b[..., 2] - b[..., 0]) + 0.5, 0.5 * (b[..., 3] - b[..., 1]) + 0.5
+            m = (((xx - cx[..., None, None]) / rx[..., None, None]) ** 2 +
+                 ((yy - cy[..., None, None]) / ry[..., None, None]) ** 2) <= 1.0
+            masks.append((m & (b[..., 4] >= 0)[..., None, None]).to(torch.uint8).contiguous())
 
     use_graph = not args.no_graph
     if use_graph:
-        model.capture(*batches[0], lr=lr, image_offset=rank * BATCH_PER_GPU)
+        model.capture(*batches[0], lr=lr, image_offset=rank * BATCH_PER_GPU, gt_masks=masks[0] if masks else None)
 
     def step(i):
         img, gt, info = batches[i % len(batches)]
+        mk = masks[i % len(batches)] if masks else None
         if use_graph:
-            return model.replay(img, gt, info, i)
-        return model.train_step(img, gt, info, step=i, image_offset=rank * BATCH_PER_GPU, lr=lr)
+            return model.replay(img, gt, info, i, gt_masks=mk)
+        return model.train_step(img, gt, info, step=i, image_offset=rank * BATCH_PER_GPU, lr=lr, gt_masks=mk)
 
     for i in range(args.warmup):
         step(i)
@@ -192,7 +210,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss_vals = [float(v) for v in torch.cat(losses).cpu().numpy()]
+    loss_vals = [float(v) for v in torch.cat(list(losses)).cpu().numpy()]
 
     # roofline pass (every rank does the same local work; the gradient exchange is switched off for it)
     fam = {}
@@ -201,7 +219,8 @@ def main():
         saved = model.reducer
         model.reducer = BucketReducer(model.arena.g, None)
         timer.logging = True
-        model.forward_backward(*batches[0], step=10 ** 6, image_offset=rank * BATCH_PER_GPU)   # eager, logged
+        model.forward_backward(*batches[0], step=10 ** 6, image_offset=rank * BATCH_PER_GPU,
+                               gt_masks=masks[0] if masks else None)   # eager, logged
         timer.logging = False
         torch.cuda.synchronize()
         fam = timer.measure()
@@ -239,19 +258,23 @@ def main():
                                            "frac": round(hfl / ht / MFMA_PEAK_BF16, 4), "traffic_bytes": traffic}
             roofline["traffic"] = traffic
         out = {
-            "metric": "images/sec (whole node) Faster R-CNN R50-FPN 3x800x1333",
+            "metric": {"faster_rcnn": "images/sec (whole node) Faster R-CNN R50-FPN 3x800x1333",
+                       "mask_rcnn": "images/sec (whole node) Mask R-CNN R50-FPN 3x800x1333",
+                       "retinanet": "images/sec (whole node) RetinaNet R101-FPN 3x800x1333"}[args.model],
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Faster R-CNN ResNet-50-FPN bf16 train step, batch 2/GPU, 3x800x1333 (padded 1344)",
+            "config": {"workload": {"faster_rcnn": "Faster R-CNN ResNet-50-FPN", "mask_rcnn": "Mask R-CNN ResNet-50-FPN",
+                                    "retinanet": "RetinaNet ResNet-101-FPN"}[args.model] +
+                       " bf16 train step, batch 2/GPU, 3x800x1333 (padded 1344)",
                        "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
                        "frozen": "stem+C2, frozen BN folded", "optimizer": "SGD momentum 0.9 wd 1e-4",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "wgrad_side_stream": not args.no_wgrad_stream,
                        "params_trainable": model.num_params()},
-            "model_mfma_roofline_frac": round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4),
-            "losses_last_step": {"rpn_cls": loss_vals[0], "rpn_reg": loss_vals[1], "rcnn_cls": loss_vals[2],
-                                 "rcnn_reg": loss_vals[3]},
+            "model_mfma_roofline_frac": (round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4)
+                                         if args.model == "faster_rcnn" else None),
+            "losses_last_step": loss_vals,
             "roofline": roofline,
             "conv_families": families,
         }
