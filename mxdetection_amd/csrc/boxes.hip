@@ -84,14 +84,16 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// NMS, stage 2: the sequential keep scan, one wave per list. Lane w owns word w of the `removed`
-// bit vector (n_max <= 4096 -> <= 64 words). Per 64-box word: one coalesced load of the diagonal
-// 64x64 block resolves the word's keep bits in registers (v_readlane, no memory in the dependent
-// chain), then the kept rows are OR-ed into the later words with independent loads.
+// NMS, stage 2: the sequential keep scan, one wave per list. The `removed` bit vector (<= 64 words) lives in LDS.
+// Per 64-box word: the diagonal 64x64 block (one coalesced load, prefetched one word ahead) resolves the word's keep
+// bits in registers (v_readlane, no memory in the dependent chain); then every lane that owns a kept box ORs that
+// box's mask row into the later words with LDS atomics -- a loop with a uniform trip count whose loads are all
+// independent, instead of a data-dependent chain of dependent loads.
 __global__ void __launch_bounds__(64)
 nms_scan_kernel(const unsigned long long* __restrict__ mask, const int32_t* __restrict__ counts,
                 const uint8_t* __restrict__ invalid, int n_max, int nwords_max, int max_keep,
                 int32_t* __restrict__ keep_idx, int32_t* __restrict__ num_keep) {
+  __shared__ unsigned long long rem[64];
   const int b = blockIdx.x, lane = threadIdx.x;
   int n = counts[b];
   n = n > n_max ? n_max : n;
@@ -99,18 +101,24 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, const int32_t* __re
   const int nw = (n + 63) >> 6;
   const unsigned long long* m = mask + (int64_t)b * n_max * nwords_max;
   // initial removed bits: invalid boxes and the tail beyond n
-  unsigned long long removed = 0;
   for (int w = 0; w < nw; ++w) {
     int idx = w * 64 + lane;
     bool bad = (idx >= n) || (invalid != nullptr && invalid[(int64_t)b * n_max + idx] != 0);
     unsigned long long bm = __ballot(bad);
-    if (lane == w) removed = bm;
+    if (lane == 0) rem[w] = bm;
   }
+  __syncthreads();   // single-wave workgroup: orders the LDS writes above against the reads below
   unsigned long long mykeep = 0;
+  unsigned long long diag_next = (nw > 0 && lane < n) ? m[(int64_t)lane * nwords_max] : 0ull;
   for (int w = 0; w < nw; ++w) {
-    unsigned long long cur = readlane64(removed, w);
-    int row = w * 64 + lane;
-    unsigned long long diag = (row < n) ? m[(int64_t)row * nwords_max + w] : 0ull;
+    const unsigned long long diag = diag_next;
+    if (w + 1 < nw) {
+      int row = (w + 1) * 64 + lane;
+      diag_next = (row < n) ? m[(int64_t)row * nwords_max + (w + 1)] : 0ull;
+    }
+    __syncthreads();   // the LDS atomics of the previous words have landed (one wave: a cheap s_barrier)
+    unsigned long long cur = rem[w];
+    cur = readlane64(cur, 0);
     unsigned long long keepbits = 0;
     for (int bb = 0; bb < 64; ++bb) {
       unsigned long long d = readlane64(diag, bb);
@@ -120,12 +128,11 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, const int32_t* __re
       }
     }
     if (lane == w) mykeep = keepbits;
-    if (lane > w && lane < nw) {
-      unsigned long long kb = keepbits;
-      while (kb) {
-        int bb = __ffsll((long long)kb) - 1;
-        kb &= kb - 1;
-        removed |= m[(int64_t)(w * 64 + bb) * nwords_max + lane];
+    if ((keepbits >> lane) & 1ull) {
+      const unsigned long long* row = m + (int64_t)(w * 64 + lane) * nwords_max;
+      for (int j = w + 1; j < nw; ++j) {
+        unsigned long long v = row[j];
+        if (v) atomicOr(&rem[j], v);
       }
     }
   }

@@ -69,11 +69,20 @@ proposal_topk_kernel(PyramidDev p, long long A_total, const unsigned* __restrict
     return true;
   };
   SelectResult sel = block_select_threshold(nl, pre_n, nbits, keyf, sm);
-  for (int i = threadIdx.x; i < nl; i += blockDim.x) {
-    unsigned fk = fk_l[i];
-    if (sel.chosen((~fk) & keymask, (unsigned)i)) {
-      int pos = atomicAdd(&n_sel, 1);
-      list[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
+  for (int i0 = threadIdx.x; i0 < nl; i0 += 4 * blockDim.x) {
+    unsigned fk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + u * blockDim.x;
+      fk[u] = i < nl ? fk_l[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + u * blockDim.x;
+      if (i < nl && sel.chosen((~fk[u]) & keymask, (unsigned)i)) {
+        int pos = atomicAdd(&n_sel, 1);
+        list[pos] = ((unsigned long long)fk[u] << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
+      }
     }
   }
   __syncthreads();

@@ -50,9 +50,18 @@ __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, K
   for (int shift = 24; shift >= 32 - nbits; shift -= 8) {
     for (int i = tid; i < 256; i += nt) sm.hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-      unsigned kv;
-      if (keyf(i, kv) && (kv & mask) == prefix) atomicAdd(&sm.hist[(kv >> shift) & 255u], 1u);
+    // 4 independent key fetches in flight per thread before the LDS atomics (the pass is latency bound)
+    for (int i0 = tid; i0 < n; i0 += 4 * nt) {
+      unsigned kv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * nt;
+        ok[u] = (i < n) && keyf(i, kv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u] && (kv[u] & mask) == prefix) atomicAdd(&sm.hist[(kv[u] >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -100,10 +109,18 @@ __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, K
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int i = tid; i < 256; i += nt) sm.hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-      unsigned kv;
-      const unsigned ix = idxf(i);
-      if ((ix & im) == ip && keyf(i, kv) && kv == T) atomicAdd(&sm.hist[(ix >> shift) & 255u], 1u);
+    for (int i0 = tid; i0 < n; i0 += 4 * nt) {
+      unsigned kv[4], ix[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * nt;
+        ok[u] = (i < n) && keyf(i, kv[u]);
+        ix[u] = (i < n) ? idxf(i) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u] && kv[u] == T && (ix[u] & im) == ip) atomicAdd(&sm.hist[(ix[u] >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid == 0) {
