@@ -49,13 +49,7 @@ class FPN:
             res = inner[i + 1] if i + 1 < L else None
             inner[i] = self.lats[i].forward(feats[i], residual=res, res_upsample=res is not None,
                                             out=self._buf("inner%d" % i, shape))
-        P = [None] * L
-
-        def out_level(i):
-            def run():
-                P[i] = self.outs[i].forward(inner[i], out=self._buf("P%d" % i, inner[i].shape))
-            return run
-        self.outs[0].ws.parallel([out_level(i) for i in range(L)])
+        P = [self.outs[i].forward(inner[i], out=self._buf("P%d" % i, inner[i].shape)) for i in range(L)]
         if self.extra_p6:
             N, H, W, Cc = P[-1].shape
             P.append(dense.subsample2(P[-1], self._buf("P6", (N, (H + 1) // 2, (W + 1) // 2, Cc))))
@@ -70,26 +64,18 @@ class FPN:
         if self.extra_p6:
             dense.subsample2_backward(dP[L], dP[L - 1], accumulate=True)
         dinner = [None] * L
-
-        def out_level(i):
-            def run():
-                self.outs[i].backward_weight(self.inner[i], dP[i])
-                dinner[i] = self.outs[i].backward_data(dP[i], self.inner[i].shape,
-                                                       out=self._buf("dinner%d" % i, self.inner[i].shape))
-            return run
-        self.outs[0].ws.parallel([out_level(i) for i in range(L)])       # independent per level
-        for i in range(1, L):                                           # top-down adjoint: a sequential chain
-            dense.upsample2_backward(dinner[i - 1], dinner[i], accumulate=True)
-
-        def lat_level(i):
-            def run():
-                self.lats[i].backward_weight(self.feats[i], dinner[i])
-                if c_needs_grad[i]:
-                    top = i == L - 1
-                    self.lats[i].backward_data(dinner[i], self.feats[i].shape,
-                                               relu_mask=self.feats[i] if top else None, out=dC[i])
-            return run
-        self.outs[0].ws.parallel([lat_level(i) for i in range(L)])
+        for i in range(L):
+            self.outs[i].backward_weight(self.inner[i], dP[i])
+            dinner[i] = self.outs[i].backward_data(dP[i], self.inner[i].shape,
+                                                   out=self._buf("dinner%d" % i, self.inner[i].shape))
+            if i > 0:
+                dense.upsample2_backward(dinner[i - 1], dinner[i], accumulate=True)
+        for i in range(L):
+            self.lats[i].backward_weight(self.feats[i], dinner[i])
+            if c_needs_grad[i]:
+                top = i == L - 1
+                self.lats[i].backward_data(dinner[i], self.feats[i].shape, relu_mask=self.feats[i] if top else None,
+                                           out=dC[i])
 
 
 class RetinaFPN:

@@ -66,15 +66,12 @@ class RPNHead:
 
     def forward(self, P):
         self.P = P
-        self.t, self.h = [None] * len(P), [None] * len(P)
-
-        def level(l):
-            def run():
-                p = P[l]
-                self.t[l] = self.conv.forward(p, relu=True, out=self._buf("t%d" % l, p.shape))
-                self.h[l] = self.out.forward(self.t[l], out=self._buf("h%d" % l, p.shape[:3] + (HEAD_CPAD,)))
-            return run
-        self.conv.ws.parallel([level(l) for l in range(len(P))])     # pyramid levels are independent
+        self.t, self.h = [], []
+        for l, p in enumerate(P):
+            t = self.conv.forward(p, relu=True, out=self._buf("t%d" % l, p.shape))
+            h = self.out.forward(t, out=self._buf("h%d" % l, p.shape[:3] + (HEAD_CPAD,)))
+            self.t.append(t)
+            self.h.append(h)
         return self.h
 
     def get_proposals(self, im_info):
@@ -99,21 +96,11 @@ class RPNHead:
         return self.loss
 
     def backward(self, dP, dP_has_grad):
-        """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False). The data-gradient
-        chains of the levels are independent (run on the stream pool); the weight gradients accumulate over levels
-        in issue order on the single side stream."""
-        def level(l):
-            def run():
-                acc = l > 0
-                self.out.backward_weight(self.t[l], self.gh[l], accumulate=acc)
-                d_t = self.out.backward_data(self.gh[l], self.t[l].shape, relu_mask=self.t[l],
-                                             out=self._buf("dt%d" % l, self.t[l].shape))
-                self.conv.backward_weight(self.P[l], d_t, accumulate=acc)
-                self.conv.backward_data(d_t, self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])
-            return run
-        ws = self.conv.ws
-        if ws.side is None and getattr(ws, "pool", None):
-            for l in range(len(self.h)):     # without the side stream the accumulating wgrads must stay ordered
-                level(l)()
-        else:
-            ws.parallel([level(l) for l in range(len(self.h))])
+        """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False)."""
+        for l in range(len(self.h)):
+            acc = l > 0
+            self.out.backward_weight(self.t[l], self.gh[l], accumulate=acc)
+            d_t = self.out.backward_data(self.gh[l], self.t[l].shape, relu_mask=self.t[l],
+                                         out=self._buf("dt%d" % l, self.t[l].shape))
+            self.conv.backward_weight(self.P[l], d_t, accumulate=acc)
+            self.conv.backward_data(d_t, self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])

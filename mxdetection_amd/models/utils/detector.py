@@ -55,11 +55,9 @@ class DetectorBase:
             self._tr_table = dense.make_transpose_table(pairs, self.device)
         dense.filter_transpose_batched(*self._tr_table)
 
-    def enable_wgrad_stream(self, level_pool=3):
-        """Issue weight-gradient kernels on a second stream (overlaps them with the data-gradient chain) and run
-        independent pyramid levels on a pool of `level_pool` extra streams."""
+    def enable_wgrad_stream(self):
+        """Issue weight-gradient kernels on a second stream (overlaps them with the data-gradient chain)."""
         self.ws.side = torch.cuda.Stream()
-        self.ws.pool = [torch.cuda.Stream() for _ in range(level_pool)]
 
     def enable_data_parallel(self, world_size):
         import torch.distributed as dist

@@ -30,26 +30,6 @@ class Workspace:
         self.buf = None
         self.side = None
 
-    def parallel(self, fns):
-        """Run independent branches (e.g. pyramid levels) on a small pool of streams forked from the current stream
-        and join them again; sequential when no pool is enabled. Small levels launch only tens of workgroups, so
-        running them beside the P2-level kernels fills otherwise idle CUs."""
-        pool = getattr(self, "pool", None)
-        if not pool:
-            for fn in fns:
-                fn()
-            return
-        main = torch.cuda.current_stream()
-        used = pool[:min(len(pool), len(fns) - 1)]
-        for st in used:
-            st.wait_stream(main)          # fork BEFORE the main stream gets its own branch
-        for i in range(1, len(fns)):
-            with torch.cuda.stream(used[(i - 1) % len(used)]):
-                fns[i]()
-        fns[0]()                          # the first (largest) branch stays on the main stream
-        for st in used:
-            main.wait_stream(st)
-
     def fork(self):
         if self.side is None:
             return None
