@@ -123,6 +123,10 @@ def load():
         raise MxdetError(
             "libmxdet_hip.so not found at %s -- build it with `python -m mxdetection_amd.build` "
             "(there is no CPU fallback)" % LIB_PATH)
+    # torch owns device memory and streams on the host side and bundles its own libamdhip64/libhsa-runtime64 with
+    # the same SONAME as /opt/rocm's. It must be mapped FIRST so that this library's DT_NEEDED entries resolve to
+    # the runtime torch uses; two HIP/HSA runtimes in one process leave the second one without a device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name, None)  # tests/test_abi.py asserts that no declared symbol is missing

@@ -351,6 +351,10 @@ static int launch(ConvP& p, hipStream_t s) {
     case 6: return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
     case 7: return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
     case 8: return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
+    case 10: return launch_cfg<64, 128, 2, 4, 2, DGRAD>(p, s);    // 8 waves, 32x32 per wave
+    case 11: return launch_cfg<128, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 32x64 per wave
+    case 12: return launch_cfg<64, 64, 2, 2, 2, DGRAD>(p, s);     // 32 KiB LDS: 5 workgroups per CU
+    case 13: return launch_cfg<128, 128, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 64x32 per wave
     default: break;
   }
   if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
