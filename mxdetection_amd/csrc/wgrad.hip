@@ -10,9 +10,15 @@
 // columns of the LDS image: they are fetched with ds_read_b64_tr_b16 (the CDNA4 transposing LDS
 // read), two per fragment. LDS images are [pixel][128 ch] with the 32-B granule index XOR-swizzled
 // by (row&3)|((row>>3)&1)<<2, which makes every transposed read conflict-free.
-// The pixel range is split over `ksplit` workgroups per tile; each writes an fp32 slab and a second
-// kernel adds the slabs in index order (bit-reproducible, no float atomics) and optionally accumulates
-// into dw (filters shared across pyramid levels: RPN head).
+// The pixel range is split over `ksplit` workgroups per tile; each writes an fp32 slab and a second kernel adds
+// the slabs in index order (bit-reproducible, no float atomics) and optionally accumulates into dw (filters
+// shared across pyramid levels: RPN head); with one split the tile goes straight to dw. The bias gradient
+// (column sums of dy) rides along as co_tiles*ksplit extra workgroups appended to the same grid (a ones-vector
+// MFMA inside the main loop was measured first: +16 accumulators took the kernel from 120 to 176 registers and
+// halved its occupancy) and is folded over the splits by the same second kernel.
+// (A "last workgroup of the tile folds the slabs" epilogue was measured and dropped: the device-scope fence it
+// needs is buffer_wbl2 + buffer_inv of the whole XCD L2 per workgroup, which destroys the tap-sharing L2 reuse
+// -- 2.3 -> 8.9 ms per step.)
 #include "common.h"
 
 namespace mxdet {
@@ -26,9 +32,14 @@ struct WgradP {
   const uint16_t* x;   // [N,H,W,Cin]
   const uint16_t* dy;  // [N,Ho,Wo,Cout]
   float* slab;         // [ksplit][Cout][KH*KW*Cin]
+  float* bslab;        // [ksplit][Cout] bias-gradient partials (db != null)
+  float* dw;           // [Cout][KH*KW*Cin]
+  float* db;           // [Cout] or null
+  int accumulate;
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
   int M;               // N*Ho*Wo
   int co_tiles, ci_tiles, ksplit, steps_per_split;
+  int nwg_main;        // MFMA workgroups; the grid continues with co_tiles*ksplit bias workgroups when db != null
 };
 
 // 16 bytes of zeros read by out-of-range lanes, so that every global load is unconditional (a branch around a
@@ -54,7 +65,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // of step t+1 are in flight while step t is multiplied; one s_waitcnt vmcnt(0) + one raw s_barrier per step.
 // The LDS image is lane-linear, so the granule swizzle is applied to the per-lane SOURCE chunk.
 template <int BKP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 wgrad_kernel(WgradP p) {
   constexpr int GI = BKP / 16;      // DMA instructions per wave per image per stage (4 pixel rows each)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][BKP * 256];  // [buf][dy|x]
@@ -64,8 +75,40 @@ wgrad_kernel(WgradP p) {
   // XCD-aware order with the tap fastest: the KH*KW workgroups that share one (dy tile, shifted x tile)
   // pair sit next to each other in one XCD's queue and hit that XCD's L2 for 8 of 9 reads.
   int b = blockIdx.x;
+  if (b >= p.nwg_main) {
+    // bias-gradient workgroups (appended to the grid, they stream dy while the MFMA workgroups compute):
+    // column sums of this split's pixel range for one 128-channel co tile, fixed order
+    b -= p.nwg_main;
+    const int co_t = b % p.co_tiles, ks = b / p.co_tiles;
+    const int c8 = tid & 15, r0 = tid >> 4;              // 16 x 16-B chunks, 16 pixel rows in flight
+    const int co = co_t * 128 + c8 * 8;
+    int m0 = ks * p.steps_per_split * BKP, m1 = m0 + p.steps_per_split * BKP;
+    m1 = m1 > p.M ? p.M : m1;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (co < p.Cout)
+      for (int m = m0 + r0; m < m1; m += 16) {
+        uint4 v = *(const uint4*)(p.dy + (size_t)m * p.Cout + co);
+        s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+        s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+        s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+        s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+      }
+    float* red = (float*)&smem[0][0][0];                  // [16 rows][128 ch]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[r0 * 128 + c8 * 8 + k] = s[k];
+    __syncthreads();
+    if (tid < 128 && co_t * 128 + tid < p.Cout) {
+      float t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) t += red[r * 128 + tid];
+      const int c = co_t * 128 + tid;
+      if (p.ksplit == 1) p.db[c] = p.accumulate ? p.db[c] + t : t;
+      else p.bslab[(size_t)ks * p.Cout + c] = t;
+    }
+    return;
+  }
   {
-    const int nwg = gridDim.x;
+    const int nwg = p.nwg_main;
     int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
     b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -188,9 +231,12 @@ wgrad_kernel(WgradP p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // slab[ks][co][tap][ci]; D layout: col = lane&15 -> ci, row = (lane>>4)*4 + r -> co
+  // D layout: col = lane&15 -> ci, row = (lane>>4)*4 + r -> co
   const size_t Ktot = (size_t)p.KH * p.KW * p.Cin;
-  float* slab = p.slab + (size_t)ks * p.Cout * Ktot;
+  const bool single = p.ksplit == 1;
+  // one split: the tile goes straight to dw/db; otherwise to this split's slab
+  float* out = single ? p.dw : p.slab + (size_t)ks * p.Cout * Ktot;
+  const bool add_old = single && p.accumulate;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -199,19 +245,45 @@ wgrad_kernel(WgradP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int co = co0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (co < p.Cout && ci < p.Cin) slab[(size_t)co * Ktot + (size_t)tap * p.Cin + ci] = acc[i][j][r];
+        if (co < p.Cout && ci < p.Cin) {
+          size_t o = (size_t)co * Ktot + (size_t)tap * p.Cin + ci;
+          out[o] = add_old ? out[o] + acc[i][j][r] : acc[i][j][r];
+        }
       }
     }
 }
 
-// dw[i] (+)= sum_ks slab[ks][i]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int ksplit, long long n,
-                                    int accumulate, float* __restrict__ dw) {
+// dw[i] (+)= sum_ks slab[ks][i] in index order; the trailing workgroups fold the bias partials the same way.
+// Four independent 16-B loads in flight per thread (the slabs are read exactly once: latency, not bandwidth, bounds
+// a small grid).
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, int ksplit, long long n,
+                    int Cout, int wblocks, int accumulate, float* __restrict__ dw, float* __restrict__ db) {
+  if ((int)blockIdx.x >= wblocks) {
+    int c = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (c >= Cout) return;
+    float s = bslab[c];
+    for (int k = 1; k < ksplit; ++k) s += bslab[(size_t)k * Cout + c];
+    db[c] = accumulate ? db[c] + s : s;
+    return;
+  }
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  float4 s = *(const float4*)(slab + i);
-  for (int k = 1; k < ksplit; ++k) {
-    float4 v = *(const float4*)(slab + (long long)k * n + i);
+  const float* sp = slab + i;
+  float4 s = *(const float4*)sp;
+  int k = 1;
+  for (; k + 3 < ksplit; k += 4) {
+    float4 v0 = *(const float4*)(sp + (long long)k * n);
+    float4 v1 = *(const float4*)(sp + (long long)(k + 1) * n);
+    float4 v2 = *(const float4*)(sp + (long long)(k + 2) * n);
+    float4 v3 = *(const float4*)(sp + (long long)(k + 3) * n);
+    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+  }
+  for (; k < ksplit; ++k) {
+    float4 v = *(const float4*)(sp + (long long)k * n);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   if (accumulate) {
@@ -219,55 +291,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int ksplit, 
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
   }
   *(float4*)(dw + i) = s;
-}
-
-// bias gradient: column sums of dy [M][C] in two fixed-order stages
-__global__ void __launch_bounds__(256)
-colsum_partial_kernel(const uint16_t* __restrict__ dy, int M, int C, int rows_per_block,
-                      float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* red = (float*)smem_raw;   // [row lanes][C]
-  const int CG = C >> 3;
-  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
-  const int RL = 256 / CG;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int m0 = blockIdx.x * rows_per_block;
-  int m1 = m0 + rows_per_block;
-  m1 = m1 > M ? M : m1;
-  if (rl < RL)
-    for (int m = m0 + rl; m < m1; m += RL) {
-      uint4 v = *(const uint4*)(dy + (size_t)m * C + cg * 8);
-      s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
-      s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
-      s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
-      s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
-    }
-  if (rl < RL)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[rl * C + cg * 8 + k] = s[k];
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float t = 0.f;
-    for (int r = 0; r < RL; ++r) t += red[r * C + c];
-    partial[(size_t)blockIdx.x * C + c] = t;
-  }
-}
-// 64 channels x 4 partial-lanes per workgroup; lanes summed in fixed order -> deterministic
-__global__ void __launch_bounds__(256)
-colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C, int accumulate,
-                    float* __restrict__ db) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float t = 0.f;
-  if (c < C)
-    for (int b = part; b < nblocks; b += 4) t += partial[(size_t)b * C + c];
-  red[part][cl] = t;
-  __syncthreads();
-  if (part == 0 && c < C) {
-    float v = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
-    db[c] = accumulate ? db[c] + v : v;
-  }
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]
@@ -322,8 +345,7 @@ __global__ void filter_transpose_batched_kernel(const TransposeDesc* __restrict_
 
 struct WgradPlan {
   int co_tiles, ci_tiles, taps, ksplit, steps_per_split;
-  size_t slab_bytes, colsum_off, colsum_bytes, total;
-  int colsum_blocks, colsum_rows;
+  size_t slab_bytes, bslab_off, bslab_bytes, total;
 };
 
 static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
@@ -344,11 +366,9 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
   w.ksplit = ceil_div(steps, w.steps_per_split);
   size_t params = (size_t)d->Cout * w.taps * d->Cin;
   w.slab_bytes = align_up((size_t)w.ksplit * params * sizeof(float), 256);
-  w.colsum_rows = 256;
-  w.colsum_blocks = (int)ceil_div<long long>(M, w.colsum_rows);
-  w.colsum_off = w.slab_bytes;
-  w.colsum_bytes = align_up((size_t)w.colsum_blocks * d->Cout * sizeof(float), 256);
-  w.total = w.slab_bytes + w.colsum_bytes;
+  w.bslab_off = w.slab_bytes;
+  w.bslab_bytes = align_up((size_t)w.ksplit * d->Cout * sizeof(float), 256);
+  w.total = w.slab_bytes + w.bslab_bytes;
   return w;
 }
 
@@ -382,30 +402,29 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
   WgradPlan w = plan_wgrad(d);
   MXDET_REQUIRE(workspace && workspace_bytes >= w.total, MXDET_EWORKSPACE,
                 "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, w.total);
-  MXDET_REQUIRE(!db || d->Cout <= 2048, MXDET_ESHAPE, "conv2d_wgrad: bias gradient supports Cout <= 2048");
+  MXDET_REQUIRE(d->Cin % 4 == 0, MXDET_ESHAPE, "conv2d_wgrad: Cin must be a multiple of 4");
   hipStream_t s = as_stream(stream);
+  const long long tiles = (long long)w.co_tiles * w.ci_tiles * w.taps;
   WgradP p;
   p.x = x; p.dy = dy; p.slab = (float*)workspace;
+  p.bslab = (float*)((char*)workspace + w.bslab_off);
+  p.dw = dw; p.db = db; p.accumulate = d->accumulate;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
   p.M = d->N * d->Ho * d->Wo;
   p.co_tiles = w.co_tiles; p.ci_tiles = w.ci_tiles; p.ksplit = w.ksplit;
   p.steps_per_split = w.steps_per_split;
-  long long nwg = (long long)w.co_tiles * w.ci_tiles * w.taps * w.ksplit;
+  long long nwg = tiles * w.ksplit;
+  p.nwg_main = (int)nwg;
+  if (db) nwg += (long long)w.co_tiles * w.ksplit;
   hipLaunchKernelGGL(wgrad_kernel<kWgradBKP>, dim3((unsigned)nwg), dim3(256), 0, s, p);
-  long long params = (long long)d->Cout * w.taps * d->Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div<long long>(params / 4, 256)), dim3(256),
-                     0, s, (const float*)workspace, w.ksplit, params, d->accumulate, dw);
-  if (db) {
-    float* partial = (float*)((char*)workspace + w.colsum_off);
-    int CG = d->Cout / 8;
-    int RL = 256 / CG > 0 ? 256 / CG : 1;
-    MXDET_REQUIRE(CG <= 256, MXDET_ESHAPE, "conv2d_wgrad: bias gradient supports Cout <= 2048");
-    size_t lds = (size_t)RL * d->Cout * sizeof(float);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(w.colsum_blocks), dim3(256), lds, s, dy, p.M, d->Cout,
-                       w.colsum_rows, partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d->Cout, 64)), dim3(256), 0, s,
-                       (const float*)partial, w.colsum_blocks, d->Cout, d->accumulate, db);
+  if (w.ksplit > 1) {
+    long long params = (long long)d->Cout * w.taps * d->Cin;
+    int wblocks = (int)ceil_div<long long>(params / 4, 256);
+    int bblocks = db ? ceil_div(d->Cout, 256) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, s,
+                       (const float*)p.slab, (const float*)p.bslab, w.ksplit, params, d->Cout, wblocks,
+                       d->accumulate, dw, db);
   }
   return check_launch("conv2d_wgrad");
 }
