@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-conv-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the main stream")
+    ap.add_argument("--no-branch-stream", action="store_true", help="keep the RPN training branch on the main stream")
     ap.add_argument("--model", default="faster_rcnn", choices=["faster_rcnn", "mask_rcnn", "retinanet"],
                     help="faster_rcnn = BASELINE.json headline (configs 1-3); mask_rcnn = config 4; retinanet = config 5 (R101)")
     args = ap.parse_args()
@@ -160,6 +161,8 @@ def main():
         model = FasterRCNN(device, depth=50, seed=7, with_mask=(args.model == "mask_rcnn"))
     if not args.no_wgrad_stream:
         model.enable_wgrad_stream()
+    if not args.no_branch_stream:
+        model.enable_branch_stream()
     if dist is not None:
         model.enable_data_parallel(world)
         dist.broadcast(model.arena.w, 0)
@@ -271,6 +274,7 @@ def main():
                        "frozen": "stem+C2, frozen BN folded", "optimizer": "SGD momentum 0.9 wd 1e-4",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "wgrad_side_stream": not args.no_wgrad_stream,
+                       "rpn_branch_stream": not args.no_branch_stream,
                        "params_trainable": model.num_params()},
             "model_mfma_roofline_frac": (round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4)
                                          if args.model == "faster_rcnn" else None),

@@ -36,6 +36,7 @@ struct ConvP {
   int relu, res_up;
   int M;
   int tiles_m, tiles_n;
+  int m_begin;     // first output row of this launch (a layer may be covered by two launches with different tiles)
   int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
 };
 
@@ -86,7 +87,7 @@ conv_igemm_kernel(ConvP p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-lane gather geometry: lane l of DMA instruction j fills row 8j + (l>>3), 16-B slot l&7 -------
   // The address math is hoisted out of the K loop (the loop was VALU-issue bound on it): per row a base
@@ -325,7 +326,7 @@ static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_con
 
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
 static int launch_cfg(ConvP& p, hipStream_t s) {
-  p.tiles_m = ceil_div(p.M, BM);
+  if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);   // caller may restrict the row range
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD>), dim3((unsigned)nwg), dim3(64 * WM * WN),
@@ -355,10 +356,30 @@ static int launch(ConvP& p, hipStream_t s) {
     case 11: return launch_cfg<128, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 32x64 per wave
     case 12: return launch_cfg<64, 64, 2, 2, 2, DGRAD>(p, s);     // 32 KiB LDS: 5 workgroups per CU
     case 13: return launch_cfg<128, 128, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 64x32 per wave
+    case 14: return launch_cfg<64, 128, 2, 2, 3, DGRAD>(p, s);    // 72 KiB: two workgroups per CU, prefetch distance 2
+    case 15: return launch_cfg<256, 256, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 128x64 per wave, 128 KiB
+    case 16: return launch_cfg<256, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 64x64 per wave, 96 KiB
+    case 17: return launch_cfg<256, 128, 2, 2, 2, DGRAD>(p, s);   // 4 waves, 128x64 per wave, 96 KiB
     default: break;
   }
   if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
-  if (t128 >= 1536 && K > 256) return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+  if (t128 >= 1536 && K > 256) {
+    // Largest layers: 256x256 tiles (one 8-wave workgroup per CU, half the LDS-DMA pieces per MFMA of the 128x128
+    // tile) for as many whole rounds of the chip's 256 CUs as the layer has; the remaining rows -- a partial round
+    // would leave most CUs idle for a whole tile time -- go to a second launch with 128x128 tiles.
+    const int tn = ceil_div(p.Ncols, 256);
+    const long long full = (long long)(p.M / 256) * tn;
+    const long long rounds = full / 256;
+    if (rounds >= 1 && p.Ncols % 256 == 0) {
+      ConvP big = p;
+      big.tiles_m = (int)(rounds * 256 / tn);
+      int rc = launch_cfg<256, 256, 2, 4, 2, DGRAD>(big, s);
+      if (rc) return rc;
+      p.m_begin = big.tiles_m * 256;
+      if (p.m_begin >= p.M) return rc;
+    }
+    return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+  }
   if (t64 >= 400) return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
   return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
 }

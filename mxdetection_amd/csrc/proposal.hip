@@ -48,16 +48,23 @@ __global__ void proposal_gather_kernel(PyramidDev p, int N, long long A_total, u
 }
 
 // (1) top-k per (level, image). keys out: (float_key(score) << 32) | (0xFFFFFFFF - global_index)
+// Three passes over the level's dense keys: two 8-bit histogram passes (bf16 logits; four for f32) find the
+// threshold key T; the third appends every key above the threshold to the LDS sort list and parks the *indices*
+// of the keys equal to T (ties -- thousands of anchors share one bf16 logit) in a second LDS list, from which the
+// `remaining` smallest are then picked without touching global memory again. Only when the ties overflow that
+// list does it fall back to the generic four index-digit passes over global memory.
+constexpr int kTieCap = 8192;
 __global__ void __launch_bounds__(1024)
 proposal_topk_kernel(PyramidDev p, long long A_total, const unsigned* __restrict__ fkeys, int pre_n, int Kpad,
                      unsigned long long* __restrict__ keys, int32_t* __restrict__ counts) {
   __shared__ SelectSmem sm;
   __shared__ unsigned long long list[kMaxPre];
-  __shared__ int n_sel;
+  __shared__ unsigned ties[kTieCap];
+  __shared__ int n_sel, n_tie;
   const int l = blockIdx.x, n = blockIdx.y;
   const int b = n * p.num_levels + l;
   const int nl = p.H[l] * p.W[l] * p.A;
-  if (threadIdx.x == 0) n_sel = 0;
+  if (threadIdx.x == 0) { n_sel = 0; n_tie = 0; }
   for (int i = threadIdx.x; i < Kpad; i += blockDim.x) list[i] = 0ull;
   __syncthreads();
   const int nbits = (p.dtype == MXDET_DTYPE_BF16) ? 16 : 32;
@@ -68,7 +75,16 @@ proposal_topk_kernel(PyramidDev p, long long A_total, const unsigned* __restrict
     kv = (~fk_l[i]) & keymask;
     return true;
   };
-  SelectResult sel = block_select_threshold(nl, pre_n, nbits, keyf, sm);
+  SelectResult sel = block_select_threshold(nl, pre_n, nbits, keyf, sm, IdentityIdx(), false);
+  const bool split_ties = sel.mode == 0 && sel.remaining < sel.eq_count;
+  const bool ties_fit = sel.eq_count <= kTieCap;
+  if (split_ties && !ties_fit) {   // rare: resolve the index threshold with the generic global passes
+    sel.IT = block_tie_threshold(nl, sel.remaining, sel.T, keyf, IdentityIdx(), sm);
+  }
+  auto emit = [&](unsigned fk, unsigned i) {
+    int pos = atomicAdd(&n_sel, 1);
+    list[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + i));
+  };
   for (int i0 = threadIdx.x; i0 < nl; i0 += 4 * blockDim.x) {
     unsigned fk[4];
 #pragma unroll
@@ -79,13 +95,29 @@ proposal_topk_kernel(PyramidDev p, long long A_total, const unsigned* __restrict
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int i = i0 + u * blockDim.x;
-      if (i < nl && sel.chosen((~fk[u]) & keymask, (unsigned)i)) {
-        int pos = atomicAdd(&n_sel, 1);
-        list[pos] = ((unsigned long long)fk[u] << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
+      if (i >= nl) continue;
+      unsigned kv = (~fk[u]) & keymask;
+      if (split_ties && ties_fit) {
+        if (kv < sel.T) emit(fk[u], (unsigned)i);
+        else if (kv == sel.T) ties[atomicAdd(&n_tie, 1)] = (unsigned)i;
+      } else if (sel.chosen(kv, (unsigned)i)) {
+        emit(fk[u], (unsigned)i);
       }
     }
   }
   __syncthreads();
+  if (split_ties && ties_fit) {
+    // the `remaining` smallest indices of the tie list (every entry has key T: only the index digits matter)
+    const int nt_ = n_tie;
+    auto tkey = [&](int, unsigned& kv) -> bool { kv = sel.T; return true; };
+    auto tidx = [&](int i) -> unsigned { return ties[i]; };
+    const unsigned IT = block_tie_threshold(nt_, sel.remaining, sel.T, tkey, tidx, sm);
+    for (int j = threadIdx.x; j < nt_; j += blockDim.x) {
+      unsigned i = ties[j];
+      if (i <= IT) emit(fk_l[i], i);
+    }
+    __syncthreads();
+  }
   block_bitonic_sort_desc(list, Kpad);
   int cnt = n_sel;
   for (int i = threadIdx.x; i < pre_n; i += blockDim.x) keys[(long long)b * pre_n + i] = list[i];

@@ -22,10 +22,31 @@ struct SelectSmem {
   int bin_count;
 };
 
+// hist[bin] += 1 for every lane with ok. Radix digits of detection scores are heavily concentrated (the top byte of
+// a logit key takes a handful of values), and same-address LDS atomics serialise 64-fold inside a wave: two rounds
+// of ballot aggregation (the first active lane's bin, then the next remaining one) take the dominant bins with one
+// atomic each; whatever is left is spread and goes the plain way.
+__device__ __forceinline__ void hist_add_agg(unsigned* hist, bool ok, unsigned bin) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    unsigned long long act = __ballot(ok);
+    if (act == 0ull) return;
+    int leader = __ffsll((long long)act) - 1;
+    unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+    bool same = ok && bin == b0;
+    unsigned long long sm_ = __ballot(same);
+    if (lane == leader) atomicAdd(&hist[b0], (unsigned)__popcll(sm_));
+    ok = ok && !same;
+  }
+  if (ok) atomicAdd(&hist[bin], 1u);
+}
+
 struct SelectResult {
   unsigned T, IT;
   int mode;    // 0: predicate above, 1: every candidate chosen, 2: none chosen
   int n_cand;  // number of candidates seen
+  int remaining, eq_count;  // of the eq_count elements with key == T, the `remaining` smallest indices are chosen
   __device__ __forceinline__ bool chosen(unsigned key, unsigned idx) const {
     return mode == 1 || (mode == 0 && (key < T || (key == T && idx <= IT)));
   }
@@ -37,12 +58,53 @@ struct SelectResult {
 // original element index so that the result does not depend on the order of the list).
 struct IdentityIdx { __device__ __forceinline__ unsigned operator()(int i) const { return (unsigned)i; } };
 
+// Among the elements with key == T, the `remaining`-th smallest index (4 radix passes over the index digits).
+template <class KeyF, class IdxF>
+__device__ inline unsigned block_tie_threshold(int n, int remaining, unsigned T, KeyF keyf, IdxF idxf, SelectSmem& sm) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  unsigned ip = 0, im = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += nt) sm.hist[i] = 0;
+    __syncthreads();
+    for (int i0 = tid; i0 < n; i0 += 4 * nt) {
+      unsigned kv[4], ix[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * nt;
+        ok[u] = (i < n) && keyf(i, kv[u]);
+        ix[u] = (i < n) ? idxf(i) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        hist_add_agg(sm.hist, ok[u] && kv[u] == T && (ix[u] & im) == ip, (ix[u] >> shift) & 255u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, b = 0;
+      for (; b < 256; ++b) {
+        int c = (int)sm.hist[b];
+        if (cum + c >= remaining && c > 0) break;
+        cum += c;
+      }
+      sm.prefix = ip | ((unsigned)b << shift);
+      sm.remaining = remaining - cum;
+    }
+    __syncthreads();
+    ip = sm.prefix;
+    remaining = sm.remaining;
+    im |= 255u << shift;
+  }
+  __syncthreads();
+  return ip;
+}
+
 template <class KeyF, class IdxF = IdentityIdx>
 __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, KeyF keyf, SelectSmem& sm,
-                                                      IdxF idxf = IdxF()) {
+                                                      IdxF idxf = IdxF(), bool resolve_ties = true) {
   const int tid = threadIdx.x, nt = blockDim.x;
   SelectResult res;
-  res.T = 0; res.IT = 0xffffffffu; res.mode = 0; res.n_cand = 0;
+  res.T = 0; res.IT = 0xffffffffu; res.mode = 0; res.n_cand = 0; res.remaining = 0; res.eq_count = 0;
   unsigned prefix = 0, mask = 0;
   int remaining = k < 0 ? 0 : k;
   int eq_count = 0;
@@ -61,7 +123,7 @@ __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, K
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (ok[u] && (kv[u] & mask) == prefix) atomicAdd(&sm.hist[(kv[u] >> shift) & 255u], 1u);
+        hist_add_agg(sm.hist, ok[u] && (kv[u] & mask) == prefix, (kv[u] >> shift) & 255u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -102,44 +164,10 @@ __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, K
     return res;
   }
   res.T = prefix;
-  if (remaining >= eq_count) return res;  // every element equal to T is taken: IT stays at max
-  // ties on T: find the `remaining`-th smallest index among the elements with key == T
-  const unsigned T = prefix;
-  unsigned ip = 0, im = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 256; i += nt) sm.hist[i] = 0;
-    __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += 4 * nt) {
-      unsigned kv[4], ix[4];
-      bool ok[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int i = i0 + u * nt;
-        ok[u] = (i < n) && keyf(i, kv[u]);
-        ix[u] = (i < n) ? idxf(i) : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u] && kv[u] == T && (ix[u] & im) == ip) atomicAdd(&sm.hist[(ix[u] >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int cum = 0, b = 0;
-      for (; b < 256; ++b) {
-        int c = (int)sm.hist[b];
-        if (cum + c >= remaining && c > 0) break;
-        cum += c;
-      }
-      sm.prefix = ip | ((unsigned)b << shift);
-      sm.remaining = remaining - cum;
-    }
-    __syncthreads();
-    ip = sm.prefix;
-    remaining = sm.remaining;
-    im |= 255u << shift;
-  }
-  __syncthreads();
-  res.IT = ip;
+  res.remaining = remaining;
+  res.eq_count = eq_count;
+  if (remaining >= eq_count || !resolve_ties) return res;  // every element equal to T is taken: IT stays at max
+  res.IT = block_tie_threshold(n, remaining, prefix, keyf, idxf, sm);
   return res;
 }
 

@@ -164,8 +164,12 @@ wgrad_kernel(WgradP p) {
       const uint16_t* ax = p.x + (unsigned)offx;
       const uint16_t* py = yok ? ay : zero;
       const uint16_t* px = xok ? ax : zero;
+#ifndef MXDET_ABL_NOLOAD
       __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(smem[buf][0] + (wid * GI + i) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(smem[buf][1] + (wid * GI + i) * 1024), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(py), "v"(px));
+#endif
       // advance this row by BKP pixels
       c_m[i] += BKP;
       c_offy[i] += stepy;
@@ -226,7 +230,11 @@ wgrad_kernel(WgradP p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+#ifndef MXDET_ABL_NOMFMA
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#else
+          asm volatile("" ::"v"(af[i]), "v"(bfr[j]));
+#endif
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -14,6 +14,7 @@ from .necks import FPN
 from .roi_extractors import FPNRoIExtractor
 from .rpn_heads import RPNHead
 from .utils.detector import DetectorBase
+from .utils.layers import Workspace
 
 
 class FasterRCNN(DetectorBase):
@@ -33,7 +34,10 @@ class FasterRCNN(DetectorBase):
         self.bbox_head = BBoxHead(7 * 7 * 256, self.arena, self.ws, device, gen, num_classes=num_classes,
                                   rois_per_image=rois_per_image, seed=rpn_seed)
         self.mark_head = self.arena.size
-        self.rpn_head = RPNHead(256, self.strides, self.arena, self.ws, device, gen, pre_nms_top_n=pre_nms_top_n,
+        # own wgrad scratch: the RPN training branch runs on its own stream (enable_branch_stream) and must not
+        # share the split-K slabs with the weight-gradient stream of the rest of the model
+        self.ws_rpn = Workspace(device)
+        self.rpn_head = RPNHead(256, self.strides, self.arena, self.ws_rpn, device, gen, pre_nms_top_n=pre_nms_top_n,
                                 post_nms_top_n=post_nms_top_n, seed=rpn_seed)
         self.mark_rpn = self.arena.size
         self.neck = FPN([256, 512, 1024, 2048], 256, self.arena, self.ws, device, gen)
@@ -65,6 +69,7 @@ class FasterRCNN(DetectorBase):
         if self.with_mask:
             self.mask_head.plan(N)
         self.ws.get()
+        self.ws_rpn.get()
         self.dP = [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in p_shapes]
         self.dC = [None] + [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in c_shapes[1:]]
         self.planned = key
@@ -76,8 +81,11 @@ class FasterRCNN(DetectorBase):
         C = self.backbone.forward(image)
         P = self.neck.forward(C)
         self.rpn_head.forward(P)
+        # The RPN training branch (anchor targets, RPN losses, RPN head backward: MFMA-heavy) depends only on the
+        # head outputs; the proposal -> RoI -> box-head chain (long, low-occupancy selection/NMS kernels) does not
+        # depend on it. They run on two streams and meet at dP. The chain is issued first: it is the longer one.
+        fork_point = self._mark_fork()
         rois, _, _, num_rois = self.rpn_head.get_proposals(im_info)
-        rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset, step_dev=step_dev)
         rois_s = self.bbox_head.sample(rois, num_rois, gt_boxes, step, image_offset, step_dev)
         pooled = self.roi_extractor.forward(P, rois_s)
         self.bbox_head.forward(pooled)
@@ -92,16 +100,16 @@ class FasterRCNN(DetectorBase):
         # ---- backward ----
         if self.with_mask:
             d_mpooled = self.mask_head.backward()
-            self._reduce(0, self.mark_mask)
         d_pooled = self.bbox_head.backward()
-        self._reduce(self.mark_mask, self.mark_head)
+        acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
         if self.with_mask:
-            acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
-            self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=True)
-        else:
-            self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4])
-        self.rpn_head.backward(self.dP, [True, True, True, True, False])
-        self._reduce(self.mark_head, self.mark_rpn)
+            self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=False)
+        with self._fork_branch(fork_point):
+            rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset, step_dev=step_dev)
+            self.rpn_head.backward(self.dP, [False] * 5)
+        self._join_branch()
+        self.roi_extractor.finalize(self.dP[:4], accumulate=True)     # dP[l] = RPN part + RoI part
+        self._reduce(0, self.mark_rpn)
         self.neck.backward(self.dP, self.dC, [False, True, True, True])
         self._reduce(self.mark_rpn, self.mark_fpn)
         lo = self.mark_fpn

@@ -39,6 +39,10 @@ class FPNRoIExtractor:
                 a.zero_()
         roi_align_backward(self.dacc, self.scales, self.rois, self.levels, grad_out, self.sr, self.lvl_min)
         if finalize:
-            for a, d in zip(self.dacc, dP):
-                dense.f32_accum_to_bf16(a, d, accumulate=False)
+            self.finalize(dP)
         return self.dacc
+
+    def finalize(self, dP, accumulate=False):
+        """dP[l] (+)= accumulators, rounded once to bf16."""
+        for a, d in zip(self.dacc, dP):
+            dense.f32_accum_to_bf16(a, d, accumulate=accumulate)

@@ -1,5 +1,7 @@
 """Shared training-step machinery of the detectors: parameter arena bookkeeping, bucketed gradient exchange, hipGraph
 capture / replay of the whole step, side-stream weight gradients, optimizer step."""
+import contextlib
+
 import torch
 
 from .dp import BucketReducer
@@ -19,6 +21,7 @@ class DetectorBase:
         self._cur_graph = None
         self._tr_table = None
         self.static_extra = {}
+        self.branch = None
 
     def _finalize_params(self, layers, frozen_layers=()):
         self.layers = layers
@@ -58,6 +61,31 @@ class DetectorBase:
     def enable_wgrad_stream(self):
         """Issue weight-gradient kernels on a second stream (overlaps them with the data-gradient chain)."""
         self.ws.side = torch.cuda.Stream()
+
+    def enable_branch_stream(self):
+        """Run the RPN training branch on its own stream, concurrently with the proposal / RoI-head chain."""
+        self.branch = torch.cuda.Stream()
+
+    def _mark_fork(self):
+        """Record the point of the current stream that the branch stream will start from."""
+        if self.branch is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def _fork_branch(self, fork_point=None):
+        if self.branch is None:
+            return contextlib.nullcontext()
+        if fork_point is not None:
+            self.branch.wait_event(fork_point)
+        else:
+            self.branch.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.branch)
+
+    def _join_branch(self):
+        if self.branch is not None:
+            torch.cuda.current_stream().wait_stream(self.branch)
 
     def enable_data_parallel(self, world_size):
         import torch.distributed as dist

@@ -82,6 +82,35 @@ def test_conv_fwd_upsampled_residual(hip, oracle):
     _close(y.float().cpu().numpy(), ref, "lateral + top-down")
 
 
+def test_conv_large_layer_two_tile_sizes(hip, oracle):
+    """A layer large enough for the launcher to cover it with 256x256 tiles (whole rounds of the chip) plus a second
+    launch of 128x128 tiles over the remaining rows: forward (bias + ReLU) and dgrad (residual + mask) must match torch
+    across the seam. M = 321*321 = 103,041 rows (402 full 256-row tiles -> 256 go to the big launch), N = 256."""
+    import torch
+    from mxdetection_amd.ops import dense
+    N, H, W, Cin, Cout, K, s, p = 1, 321, 321, 64, 256, 3, 1, 1
+    rng = np.random.default_rng(11)
+    x = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+    w = _bf(rng, (Cout, K, K, Cin), (2.0 / (K * K * Cin)) ** 0.5, oracle)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    y = dense.conv2d_forward(_t(x, torch.bfloat16), _t(w, torch.bfloat16), _t(bias), None, s, p, relu=True)
+    _close(y.float().cpu().numpy(), np.maximum(_torch_conv(x, w, s, p) + bias, 0), "large fwd vs torch")
+    # dgrad of a 256 -> 256 layer of the same extent
+    Cin2 = 256
+    dy = _bf(rng, (N, H, W, Cout), 1.0, oracle)
+    w2 = _bf(rng, (Cout, K, K, Cin2), (2.0 / (K * K * Cout)) ** 0.5, oracle)
+    wt = dense.filter_transpose(_t(w2, torch.bfloat16))
+    res = _bf(rng, (N, H, W, Cin2), 1.0, oracle)
+    act = np.maximum(_bf(rng, (N, H, W, Cin2), 1.0, oracle), 0)
+    dx = dense.conv2d_dgrad(_t(dy, torch.bfloat16), wt, (N, H, W, Cin2), K, K, s, p, residual=_t(res, torch.bfloat16),
+                            relu_mask=_t(act, torch.bfloat16))
+    xt = torch.zeros((N, Cin2, H, W), requires_grad=True)
+    yt = torch.nn.functional.conv2d(xt, torch.from_numpy(w2).permute(0, 3, 1, 2), stride=s, padding=p)
+    yt.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    _close(dx.float().cpu().numpy(), (ref + res) * (act > 0), "large dgrad+res+mask vs torch")
+
+
 @pytest.mark.parametrize("case", CASES[:6])
 def test_conv_dgrad(hip, oracle, case):
     import torch
