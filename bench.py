@@ -51,9 +51,9 @@ class ConvTimer:
 
     The timed region replays hipGraphs, so per-launch events cannot sit inside it. Instead one eager step is
     logged (every conv launch with its arguments) and each logged launch is then re-issued REPS times back to back
-    on the launch stream between two HIP events (GPU saturated, no host gaps in the measurement). Algorithmic FLOPs
+    inside one hipGraph replayed between two HIP events (GPU saturated, no host launch cost in the measurement). Algorithmic FLOPs
     per launch = 2 * M * Ncols * K. rocprofv3 --kernel-trace --stats of the same command is committed under profiles/."""
-    REPS = 4
+    REPS = 8
 
     def __init__(self):
         self.log = []
@@ -93,18 +93,29 @@ class ConvTimer:
         wrap("conv2d_dgrad", "conv_igemm_dgrad", f_dgrad)
         wrap("conv2d_wgrad", "conv_wgrad", f_wgrad)
 
-    def measure(self):
+    @staticmethod
+    def time_launch(fn, a, kw, reps):
+        """Average device time of one launch: `reps` re-issues captured into a hipGraph (no host launch cost between
+        them -- a small conv is shorter than a ctypes call), one warm replay, one replay between HIP events."""
         import torch
+        fn(*a, **kw)     # warm (and plans nothing new: shapes are those of the logged step)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn(*a, **kw)
+        g.replay()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) * 1e-3 / reps
+
+    def measure(self):
         fam = {}
         for family, flops, fn, a, kw in self.log:
-            fn(*a, **kw)     # warm
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(self.REPS):
-                fn(*a, **kw)
-            e.record()
-            e.synchronize()
-            t = s.elapsed_time(e) * 1e-3 / self.REPS
+            t = self.time_launch(fn, a, kw, self.REPS)
             acc = fam.setdefault(family, [0.0, 0.0, 0])
             acc[0] += flops
             acc[1] += t
@@ -245,7 +256,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(fl / tt / 1e12, 2), "peak": 2500.0,
                         "unit": "TFLOP/s", "frac": round(fl / tt / MFMA_PEAK_BF16, 4), "traffic": None,
                         "launches_per_step": n, "avg_launch_ms": round(1e3 * tt / n, 4),
-                        "method": "each conv launch of one step re-issued 4x back-to-back between HIP events"}
+                        "method": "each conv launch of one step re-issued 8x inside a hipGraph replayed between HIP events"}
         # heaviest single launch of the dominant family (the P2-level 3x3 layer), with the HBM traffic measured for
         # exactly that launch in separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
         if roofline is not None and timer.heaviest.get(roofline["kernel"]):

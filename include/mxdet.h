@@ -283,6 +283,8 @@ int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x, const uint
 /* tuning / test hook: force the conv tile configuration on this thread (0 = built-in heuristic,
  * 1..8 = a specific tile/ring configuration, see conv.hip launch()) */
 int mxdet_debug_force_conv_cfg(int32_t cfg);
+/* Tuning hook: force the split-K factor of mxdet_conv2d_wgrad on the calling thread (0 = heuristic). */
+int mxdet_debug_force_wgrad_ksplit(int32_t ksplit);
 /* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);

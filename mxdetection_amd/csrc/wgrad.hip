@@ -64,11 +64,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 2-stage LDS-DMA ring (global_load_lds_dwordx4, 1 KiB per wave instruction = 4 pixel rows x 256 B): the loads
 // of step t+1 are in flight while step t is multiplied; one s_waitcnt vmcnt(0) + one raw s_barrier per step.
 // The LDS image is lane-linear, so the granule swizzle is applied to the per-lane SOURCE chunk.
-template <int BKP>
+template <int BKP, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 wgrad_kernel(WgradP p) {
   constexpr int GI = BKP / 16;      // DMA instructions per wave per image per stage (4 pixel rows each)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][BKP * 256];  // [buf][dy|x]
+  static_assert(NS >= 2 && (NS - 2) * 2 * (BKP / 16) <= 63, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS][2][BKP * 256];  // [buf][dy|x]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -193,49 +194,83 @@ wgrad_kernel(WgradP p) {
   // 16-channel block; it receives channel (lane&15) of those four pixel rows.
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 
-  issue_stage(0, nsteps > 0);
-  for (int st = 0; st < nsteps; ++st) {
-    const int cur = st & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's loads of step st have landed ...
-    __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done with the other buffer
-    asm volatile("" ::: "memory");
-    issue_stage(cur ^ 1, st + 1 < nsteps);
-    const unsigned char* sy = smem[cur][0];
-    const unsigned char* sx = smem[cur][1];
+  static_assert(BKP == 32, "one 32-pixel MFMA k-step per ring stage");
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&smem[0][0][0];
+  unsigned offy[4], offx[4];
+  {
+    const int rowa = 8 * g + q;                 // first 4 pixel rows of this lane group's k-range (rows +4: offset 1024)
+    const int fa = (rowa & 3) | (((rowa >> 3) & 1) << 2);
 #pragma unroll
-    for (int kk = 0; kk < BKP / 32; ++kk) {
-      const int rowa = kk * 32 + 8 * g + q;       // first 4 pixel rows of this lane group's k-range
-      const int rowb = rowa + 4;
-      const int fa = (rowa & 3) | (((rowa >> 3) & 1) << 2);
-      const int fb = (rowb & 3) | (((rowb >> 3) & 1) << 2);
-      bf16x8_t af[4], bfr[4];
-      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int cgi = wm * 4 + i;   // 16-channel granule of the co tile
-        s16x4_t lo = tr_read(sy, rowa * 256 + ((cgi ^ fa) << 5) + pp * 8);
-        s16x4_t hi = tr_read(sy, rowb * 256 + ((cgi ^ fb) << 5) + pp * 8);
-        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        af[i] = __builtin_bit_cast(bf16x8_t, v);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int cgj = wn * 4 + j;
-        s16x4_t lo = tr_read(sx, rowa * 256 + ((cgj ^ fa) << 5) + pp * 8);
-        s16x4_t hi = tr_read(sx, rowb * 256 + ((cgj ^ fb) << 5) + pp * 8);
-        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#ifndef MXDET_ABL_NOMFMA
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-#else
-          asm volatile("" ::"v"(af[i]), "v"(bfr[j]));
-#endif
+    for (int i = 0; i < 4; ++i) {
+      offy[i] = (unsigned)(rowa * 256 + (((wm * 4 + i) ^ fa) << 5) + pp * 8);   // 16-channel granule wm*4+i of the co tile
+      offx[i] = (unsigned)(rowa * 256 + (((wn * 4 + i) ^ fa) << 5) + pp * 8);
     }
+  }
+
+  // NS-deep ring: stages st+1 .. st+NS-1 are in flight while stage st is multiplied (dummy zero-page stages past
+  // the end keep the counted wait uniform)
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue_stage(s0, s0 < nsteps);
+  int cur = 0, nxt = NS - 1;
+  for (int st = 0; st < nsteps; ++st) {
+    // this wave's loads of step st have landed (all but the NS-2 youngest stages) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 2 * GI) : "memory");
+    __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done with the buffer refilled next
+    asm volatile("" ::: "memory");
+    issue_stage(nxt, st + NS - 1 < nsteps);
+    // Fragment reads in inline asm: behind the ds_read_tr builtin hipcc cannot tell that the read does not touch
+    // the ring slot an LDS-DMA is still filling and drains vmcnt(0) before the first read of every step (measured:
+    // the ring then overlaps nothing). The asm reads are ordered by hand: LDS returns in issue order, the first
+    // fence (lgkmcnt(4)) releases the x fragments and the first two dy fragments, the second the rest, so the last
+    // four reads are still in flight under the first eight MFMAs. The fences name the registers they release.
+    const unsigned sbase = smem_addr + (unsigned)cur * (2u * BKP * 256u);
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x4_t ylo[4], yhi[4], xlo[4], xhi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ad = sbase + (unsigned)(BKP * 256) + offx[j];
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[j]) : "v"(ad));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(xhi[j]) : "v"(ad));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ad = sbase + offy[i];
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[i]) : "v"(ad));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(yhi[i]) : "v"(ad));
+    }
+    s16x8_t bx[4], ay[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bx[j] = (s16x8_t){xlo[j][0], xlo[j][1], xlo[j][2], xlo[j][3], xhi[j][0], xhi[j][1], xhi[j][2], xhi[j][3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ay[i] = (s16x8_t){ylo[i][0], ylo[i][1], ylo[i][2], ylo[i][3], yhi[i][0], yhi[i][1], yhi[i][2], yhi[i][3]};
+    asm volatile("s_waitcnt lgkmcnt(4)"
+                 : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]), "+v"(ay[0]), "+v"(ay[1]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#ifndef MXDET_ABL_NOMFMA
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ay[i]),
+                                                            __builtin_bit_cast(bf16x8_t, bx[j]), acc[i][j], 0, 0, 0);
+#else
+        asm volatile("" ::"v"(ay[i]), "v"(bx[j]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);   // keep the first eight MFMAs above the second fence
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ay[2]), "+v"(ay[3]));
+#pragma unroll
+    for (int i = 2; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#ifndef MXDET_ABL_NOMFMA
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ay[i]),
+                                                            __builtin_bit_cast(bf16x8_t, bx[j]), acc[i][j], 0, 0, 0);
+#else
+        asm volatile("" ::"v"(ay[i]), "v"(bx[j]));
+#endif
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -356,6 +391,8 @@ struct WgradPlan {
   size_t slab_bytes, bslab_off, bslab_bytes, total;
 };
 
+static thread_local int g_force_ksplit = 0;   // tuning hook (mxdet_debug_force_wgrad_ksplit), 0 = heuristic
+
 static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
   WgradPlan w;
   w.co_tiles = ceil_div(d->Cout, 128);
@@ -365,11 +402,14 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
   int steps = (int)ceil_div<long long>(M, kWgradBKP);
   int tiles = w.co_tiles * w.ci_tiles * w.taps;
   // aim for ~4 workgroups per CU overall, at least 8 steps per split
-  int want = ceil_div(1024, tiles);
+  // 1024 workgroups are resident at once (4 per CU: 32 KiB of LDS, <= 128 registers); one more would run alone in
+  // a second round, so round the split DOWN
+  int want = 1024 / tiles > 0 ? 1024 / tiles : 1;
   const int min_steps = 512 / kWgradBKP;   // at least 512 pixels per split
   int maxsplit = steps / min_steps > 0 ? steps / min_steps : 1;
   int ks = want < maxsplit ? want : maxsplit;
   ks = ks < 1 ? 1 : (ks > 64 ? 64 : ks);
+  if (g_force_ksplit > 0) ks = g_force_ksplit < steps ? g_force_ksplit : steps;
   w.steps_per_split = ceil_div(steps, ks);
   w.ksplit = ceil_div(steps, w.steps_per_split);
   size_t params = (size_t)d->Cout * w.taps * d->Cin;
@@ -383,6 +423,11 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
 }  // namespace mxdet
 
 using namespace mxdet;
+
+extern "C" int mxdet_debug_force_wgrad_ksplit(int32_t ks) {
+  g_force_ksplit = ks;
+  return MXDET_OK;
+}
 
 extern "C" size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d) {
   if (!d || d->N <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->Ho <= 0 || d->Wo <= 0)
@@ -425,7 +470,11 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
   long long nwg = tiles * w.ksplit;
   p.nwg_main = (int)nwg;
   if (db) nwg += (long long)w.co_tiles * w.ksplit;
-  hipLaunchKernelGGL(wgrad_kernel<kWgradBKP>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+  // few workgroups per CU: a deeper ring hides the load latency that co-resident workgroups would otherwise hide
+  if (nwg <= 2 * 256)
+    hipLaunchKernelGGL((wgrad_kernel<kWgradBKP, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<kWgradBKP, 2>), dim3((unsigned)nwg), dim3(256), 0, s, p);
   if (w.ksplit > 1) {
     long long params = (long long)d->Cout * w.taps * d->Cin;
     int wblocks = (int)ceil_div<long long>(params / 4, 256);

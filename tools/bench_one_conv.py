@@ -13,6 +13,8 @@ N, H, W, Cin, Cout, K, s = [int(v) for v in sys.argv[2:9]]
 reps = int(sys.argv[9]) if len(sys.argv) > 9 else 20
 cfg = int(sys.argv[10]) if len(sys.argv) > 10 else 0
 _lib.load().mxdet_debug_force_conv_cfg(cfg)
+if kind == "wgrad":
+    _lib.load().mxdet_debug_force_wgrad_ksplit(cfg)
 p = K // 2
 x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
 w = (torch.randn(Cout, K, K, Cin, device="cuda") * 0.05).to(torch.bfloat16)
@@ -33,10 +35,15 @@ def run():
 for _ in range(3):
     run()
 torch.cuda.synchronize()
+# device time only: reps launches inside one hipGraph (a small conv is shorter than a ctypes call)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    for _ in range(reps):
+        run()
+g.replay()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
-for _ in range(reps):
-    run()
+g.replay()
 b.record(); b.synchronize()
 t = a.elapsed_time(b) * 1e-3 / reps
 fl = 2.0 * N * Ho * Wo * Cout * K * K * Cin

@@ -23,16 +23,9 @@ def main():
     timer.logging = False
     torch.cuda.synchronize()
     agg = {}
-    REPS = 5
+    REPS = 8
     for family, flops, fn, a, kw in timer.log:
-        fn(*a, **kw)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(REPS):
-            fn(*a, **kw)
-        e.record()
-        e.synchronize()
-        t = s.elapsed_time(e) * 1e-3 / REPS
+        t = bench.ConvTimer.time_launch(fn, a, kw, REPS)
         if family == "conv_igemm_fwd":
             x, w = a[0], a[1]
             stride = kw.get("stride", a[4] if len(a) > 4 else 1)
