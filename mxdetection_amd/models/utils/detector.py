@@ -65,21 +65,24 @@ class DetectorBase:
     def enable_branch_stream(self):
         """Run the RPN training branch on its own stream, concurrently with the proposal / RoI-head chain."""
         self.branch = torch.cuda.Stream()
+        self._branch_anchor = torch.zeros((1,), dtype=torch.int32, device=self.device)
 
     def _mark_fork(self):
-        """Record the point of the current stream that the branch stream will start from."""
+        """Fork the branch stream from the current point of the main stream. A one-element fill is issued on the branch
+        right away: under hipGraph replay a forked chain starts no earlier than its FIRST node's position in capture
+        order (measured: a branch whose first kernel was captured after the other chain simply ran after it), so the
+        branch is anchored here and the work issued later on it follows that anchor in stream order."""
         if self.branch is None:
             return None
-        ev = torch.cuda.Event()
-        ev.record()
-        return ev
+        self.branch.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.branch):
+            self._branch_anchor.zero_()
+        return True
 
     def _fork_branch(self, fork_point=None):
         if self.branch is None:
             return contextlib.nullcontext()
-        if fork_point is not None:
-            self.branch.wait_event(fork_point)
-        else:
+        if fork_point is None:
             self.branch.wait_stream(torch.cuda.current_stream())
         return torch.cuda.stream(self.branch)
 
