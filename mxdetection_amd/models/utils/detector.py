@@ -22,6 +22,9 @@ class DetectorBase:
         self._tr_table = None
         self.static_extra = {}
         self.branch = None
+        self._upd = None          # (lr, momentum, wd) while a training step wants its buckets updated as they finish
+        self._upd_done = []       # arena ranges already updated in this step
+        self._tr_ranges = {}
 
     def _finalize_params(self, layers, frozen_layers=()):
         self.layers = layers
@@ -103,8 +106,29 @@ class DetectorBase:
                 self._seg_end()
                 self.segments.append(("reduce", lo, hi))
                 self._seg_begin()
-            return
-        self.reducer.reduce(lo, hi)
+        else:
+            self.reducer.reduce(lo, hi)
+        if self._upd is not None and self.dist is None and hi > lo:
+            self._update_range(lo, hi)
+
+    def _update_range(self, lo, hi):
+        """SGD-momentum update + bf16 / transposed working copies of one finished bucket, on the weight-gradient stream:
+        nothing issued so far in this step reads these parameters any more, so the update overlaps the rest of the
+        backward pass instead of forming a serial tail after it (single-GPU path; with a gradient exchange the update
+        follows the last all-reduce, see optimizer_step)."""
+        from ...ops import dense
+        lr, momentum, wd = self._upd
+        a = self.arena
+        ctx = self.ws.fork()
+        with (ctx if ctx is not None else contextlib.nullcontext()):
+            dense.sgd_momentum_update(a.w[lo:hi], a.g[lo:hi], a.m[lo:hi], a.wb[lo:hi], lr, momentum, wd, 1.0)
+            key = (lo, hi)
+            if key not in self._tr_ranges:
+                pairs = [(l.w_bf16, l.wt) for l in self.layers if l.trainable and lo <= a.offset_of(l.wi) < hi]
+                self._tr_ranges[key] = dense.make_transpose_table(pairs, self.device) if pairs else None
+            if self._tr_ranges[key] is not None:
+                dense.filter_transpose_batched(*self._tr_ranges[key])
+        self._upd_done.append((lo, hi))
 
     # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
 
@@ -135,8 +159,10 @@ class DetectorBase:
         with torch.cuda.stream(side):
             self._cap = True
             self._seg_begin()
+            self._upd, self._upd_done = ((lr, 0.9, 1e-4) if self.dist is None else None), []
             losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
                                            gt_masks=self.static_masks)
+            self._upd = None
             self.optimizer_step(lr)
             self._seg_end()
             self._cap = False
@@ -166,6 +192,23 @@ class DetectorBase:
 
     def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
         self.ws.join()
+        done, self._upd_done = self._upd_done, []
+        if done:
+            # buckets were updated as they finished; update whatever the bucket marks did not cover
+            covered = sorted(done)
+            gaps, pos = [], 0
+            for lo, hi in covered:
+                if lo > pos:
+                    gaps.append((pos, lo))
+                pos = max(pos, hi)
+            if pos < self.arena.size:
+                gaps.append((pos, self.arena.size))
+            self._upd = (lr, momentum, wd)
+            for lo, hi in gaps:
+                self._update_range(lo, hi)
+            self._upd = None
+            self.ws.join()
+            return
         if self._cap:
             if self.dist is not None:
                 self._seg_end()
@@ -177,7 +220,12 @@ class DetectorBase:
         self.arena.sgd_step(lr, momentum, wd, rescale)
         self.refresh_transposed()
 
-    def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025, gt_masks=None):
-        losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset, gt_masks=gt_masks)
-        self.optimizer_step(lr)
+    def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025, gt_masks=None,
+                   momentum=0.9, wd=1e-4):
+        self._upd, self._upd_done = ((lr, momentum, wd) if self.dist is None else None), []
+        try:
+            losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset, gt_masks=gt_masks)
+        finally:
+            self._upd = None
+        self.optimizer_step(lr, momentum, wd)
         return losses
