@@ -211,7 +211,7 @@ extern "C" int mxdet_nms_batched(const float* boxes, const int32_t* counts, cons
   MXDET_REQUIRE(n_max <= 4096, MXDET_ESHAPE, "nms_batched: n_max %d > 4096 unsupported", n_max);
   MXDET_REQUIRE(counts && num_keep, MXDET_EINVAL, "nms_batched: null pointer");
   if (n_max == 0) {
-    hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int32_t) * B, as_stream(stream));
+    hipError_t e = zero_async(num_keep, sizeof(int32_t) * B, as_stream(stream));
     MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "nms_batched: memset failed");
     return MXDET_OK;
   }

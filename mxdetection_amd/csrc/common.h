@@ -40,6 +40,20 @@ __host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Zero `bytes` (a multiple of 4) at `p` with a kernel. Used instead of hipMemsetAsync everywhere: memset NODES of a
+// hipGraph did not order reliably against the kernels behind them once a graph started with them (a step captured
+// with the RPN branch as its own graph lost the zeroing of the anchor-sampling counters: garbage counts, GPU fault).
+__global__ static void zero_u32_kernel(unsigned* __restrict__ p, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
+  long long n = (long long)((bytes + 3) / 4);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)p, n);
+  return hipGetLastError();
+}
+
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);

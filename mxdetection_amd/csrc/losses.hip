@@ -275,7 +275,7 @@ extern "C" int mxdet_focal_loss(const void* logits, int32_t dtype, const int32_t
   hipStream_t s = as_stream(stream);
   int* cnt = (int*)workspace;
   float* partial = (float*)((char*)workspace + 256);
-  hipError_t e = hipMemsetAsync(cnt, 0, 256, s);
+  hipError_t e = zero_async(cnt, 256, s);
   MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "focal_loss: memset failed");
   hipLaunchKernelGGL(count_fg_kernel, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, s,
                      labels, (long long)n, cnt);
@@ -446,7 +446,7 @@ extern "C" int mxdet_anchor_class_labels(const int32_t* labels, const int32_t* m
   MXDET_REQUIRE(N > 0 && A_total > 0 && G_max > 0, MXDET_ESHAPE, "anchor_class_labels: bad shape");
   MXDET_REQUIRE(labels && matched_gt && gt_boxes && cls_labels && num_fg, MXDET_EINVAL, "anchor_class_labels: null pointer");
   hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(num_fg, 0, sizeof(int32_t), s);
+  hipError_t e = zero_async(num_fg, sizeof(int32_t), s);
   MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "anchor_class_labels: memset failed");
   long long total = (long long)N * A_total;
   hipLaunchKernelGGL(anchor_class_labels_kernel, dim3((unsigned)ceil_div<long long>(total, 256)), dim3(256), 0, s, labels,

@@ -169,7 +169,7 @@ extern "C" int mxdet_mask_loss(const uint16_t* logits, const int32_t* cls, const
   hipStream_t s = as_stream(stream);
   int* cnt = (int*)workspace;
   float* partial = (float*)((char*)workspace + 256);
-  hipError_t e = hipMemsetAsync(cnt, 0, 256, s);
+  hipError_t e = zero_async(cnt, 256, s);
   MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "mask_loss: memset failed");
   hipLaunchKernelGGL(count_pos_kernel, dim3((unsigned)ceil_div<long long>(R, 256)), dim3(256), 0, s, cls, (int)R, cnt);
   int blocks = (int)(((long long)R * S * S + 255) / 256);

@@ -2,7 +2,7 @@
 //
 // Slot: rpn_heads + ops (/root/reference/README.md:28, :24); MXNet role contrib.Proposal /
 // MultiProposal / the lineage's pyramid-proposal CustomOp (README.md:37). Pipeline, all on device:
-//   (1) per (image, level): radix-select top-k logits -> LDS bitonic sort by (score desc, index asc)
+//   (1) per (image, level): chip-wide radix-select of the top-k logits -> LDS bitonic sort by (score desc, index asc)
 //   (2) decode + clip + min-size flag for the selected anchors
 //   (3) batched bitmask NMS (boxes.hip)
 //   (4) per image: rank-merge of the per-level kept lists (binary searches in LDS), cut to top-N
@@ -34,11 +34,35 @@ __device__ __forceinline__ float pyr_score(const PyramidDev& p, int l, int n, in
   return load_as_f32(p.cls[l], off, p.dtype);
 }
 
-// (0) gather the objectness logits (arbitrary strides, e.g. 3 channels of a 64-channel padded row) into a dense
-// [N][A_total] array of order-preserving keys, in parallel over the whole chip: the selection passes of (1)
-// then stream 4 dense bytes per anchor instead of touching a 128-B line per cell from a single CU.
-__global__ void proposal_gather_kernel(PyramidDev p, int N, long long A_total, unsigned* __restrict__ fkeys) {
+// ---- (0)+(1): chip-wide radix selection of the pre-NMS top-k of every (image, level) -------------------------------
+// One workgroup per list (the earlier form) spends 200+ us streaming the 201,600 P2 keys through a single CU, seven
+// times. Here every pass is a grid over 4096-key chunks of all lists, a few microseconds each:
+//   gather  : logits (arbitrary strides) -> dense order-preserving keys [N][A_total]; zeroes the selection state
+//   hist p  : 8-bit digit histogram of pass p (2 passes for bf16 logits, 4 for f32), LDS per workgroup, then one
+//             global atomic per non-empty bin. The digit prefix found by the earlier passes is re-derived by every
+//             workgroup from the global histograms (one wave, 256 bins) instead of a kernel of its own.
+//   select  : keys above the threshold T go to the list's unsorted output; the INDICES of keys equal to T (ties --
+//             thousands of anchors share one bf16 logit) go to a tie list
+//   finish  : one workgroup per list: the `remaining` smallest tie indices join the output (radix passes over the tie
+//             list only), LDS bitonic sort by (score desc, index asc), write keys + count
+// Selection is integer-only and equals "the k smallest by (~key, index)": bit-exact against the oracle.
+constexpr int kSelChunk = 4096;    // keys per workgroup (256 threads x 16)
+constexpr int kMaxPasses = 4;
+
+struct SelDev {
+  unsigned* hist;     // [kMaxPasses][B][256]
+  int* cnt;           // [B][2]: n_sel, n_tie
+  unsigned* ties;     // [N][A_total], a list's ties at its level offset
+  int npass;          // 2 (bf16) or 4 (f32)
+  unsigned keymask;
+  int B, pre_n;
+};
+
+__global__ void proposal_gather_kernel(PyramidDev p, int N, long long A_total, unsigned* __restrict__ fkeys,
+                                       SelDev sd) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long long)kMaxPasses * sd.B * 256) sd.hist[idx] = 0u;
+  if (idx < (long long)sd.B * 2) sd.cnt[idx] = 0;
   if (idx >= (long long)N * A_total) return;
   int n = (int)(idx / A_total);
   long long g = idx - (long long)n * A_total;
@@ -47,80 +71,174 @@ __global__ void proposal_gather_kernel(PyramidDev p, int N, long long A_total, u
   fkeys[idx] = mxdet_float_key(pyr_score(p, l, n, (int)(g - p.level_offset[l])));
 }
 
-// (1) top-k per (level, image). keys out: (float_key(score) << 32) | (0xFFFFFFFF - global_index)
-// Three passes over the level's dense keys: two 8-bit histogram passes (bf16 logits; four for f32) find the
-// threshold key T; the third appends every key above the threshold to the LDS sort list and parks the *indices*
-// of the keys equal to T (ties -- thousands of anchors share one bf16 logit) in a second LDS list, from which the
-// `remaining` smallest are then picked without touching global memory again. Only when the ties overflow that
-// list does it fall back to the generic four index-digit passes over global memory.
-constexpr int kTieCap = 8192;
-__global__ void __launch_bounds__(1024)
-proposal_topk_kernel(PyramidDev p, long long A_total, const unsigned* __restrict__ fkeys, int pre_n, int Kpad,
-                     unsigned long long* __restrict__ keys, int32_t* __restrict__ counts) {
-  __shared__ SelectSmem sm;
-  __shared__ unsigned long long list[kMaxPre];
-  __shared__ unsigned ties[kTieCap];
-  __shared__ int n_sel, n_tie;
-  const int l = blockIdx.x, n = blockIdx.y;
-  const int b = n * p.num_levels + l;
-  const int nl = p.H[l] * p.W[l] * p.A;
-  if (threadIdx.x == 0) { n_sel = 0; n_tie = 0; }
-  for (int i = threadIdx.x; i < Kpad; i += blockDim.x) list[i] = 0ull;
+// Threshold state after `npass_done` histogram passes, derived by one wave from the global histograms.
+struct SelState {
+  unsigned prefix, mask;
+  int remaining, eq_count, all;   // all: fewer candidates than requested -> everything is chosen
+};
+
+// first bin b with hist[b] > 0 and cum(b-1) + hist[b] >= remaining; whole wave participates
+__device__ inline void wave_find_bin(const unsigned* __restrict__ hist, int remaining, int* bin, int* cum_before,
+                                     int* bin_count) {
+  const int lane = threadIdx.x & 63;
+  uint4 v = *(const uint4*)(hist + lane * 4);
+  int c[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+  int s = c[0] + c[1] + c[2] + c[3];
+  int incl = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  int excl = incl - s;
+  // lanes whose range contains the crossing: excl < remaining' <= incl  (remaining' = max(remaining,1))
+  int need = remaining > 1 ? remaining : 1;
+  bool here = s > 0 && excl < need && incl >= need;
+  unsigned long long m = __ballot(here);
+  if (m == 0ull) { *bin = 256; *cum_before = incl; *bin_count = 0; return; }
+  int src = __ffsll((long long)m) - 1;
+  int b = 0, cb = excl, bc = 0;
+  if (lane == src) {
+    int cum = excl;
+    for (int j = 0; j < 4; ++j) {
+      if (c[j] > 0 && cum + c[j] >= need) { b = lane * 4 + j; cb = cum; bc = c[j]; break; }
+      cum += c[j];
+    }
+  }
+  *bin = __shfl(b, src); *cum_before = __shfl(cb, src); *bin_count = __shfl(bc, src);
+}
+
+__device__ inline SelState sel_resolve(const SelDev& sd, int b, int npass_done, SelState* sh) {
+  if (threadIdx.x < 64) {
+    SelState st;
+    st.prefix = 0; st.mask = 0; st.remaining = sd.pre_n; st.eq_count = 0; st.all = 0;
+    for (int ps = 0; ps < npass_done && !st.all; ++ps) {
+      const int shift = 24 - 8 * ps;
+      int bin, cum, bc;
+      wave_find_bin(sd.hist + ((size_t)ps * sd.B + b) * 256, st.remaining, &bin, &cum, &bc);
+      if (bin == 256) { st.all = 1; break; }
+      st.prefix |= (unsigned)bin << shift;
+      st.mask |= 255u << shift;
+      st.remaining -= cum;
+      st.eq_count = bc;
+    }
+    if (threadIdx.x == 0) *sh = st;
+  }
   __syncthreads();
-  const int nbits = (p.dtype == MXDET_DTYPE_BF16) ? 16 : 32;
-  const unsigned keymask = (nbits == 16) ? 0xffff0000u : 0xffffffffu;
+  return *sh;
+}
+
+__global__ void __launch_bounds__(256)
+proposal_hist_kernel(PyramidDev p, long long A_total, const unsigned* __restrict__ fkeys, SelDev sd, int pass) {
+  __shared__ unsigned h[256];
+  __shared__ SelState sh;
+  const int l = blockIdx.y, n = blockIdx.z;
+  const int nl = p.H[l] * p.W[l] * p.A;
+  const int c0 = blockIdx.x * kSelChunk;
+  if (c0 >= nl) return;
+  const int b = n * p.num_levels + l;
+  h[threadIdx.x] = 0u;
+  SelState st = sel_resolve(sd, b, pass, &sh);   // contains the barrier that publishes h[] = 0
+  if (st.all) return;
+  const unsigned* fk_l = fkeys + (long long)n * A_total + p.level_offset[l];
+  const int shift = 24 - 8 * pass;
+  const int c1 = c0 + kSelChunk < nl ? c0 + kSelChunk : nl;
+  for (int i0 = c0 + threadIdx.x; i0 < c1; i0 += 4 * 256) {
+    unsigned kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + u * 256;
+      kv[u] = i < c1 ? (~fk_l[i]) & sd.keymask : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      hist_add_agg(h, (i0 + u * 256 < c1) && (kv[u] & st.mask) == st.prefix, (kv[u] >> shift) & 255u);
+  }
+  __syncthreads();
+  unsigned v = h[threadIdx.x];
+  if (v) atomicAdd(&sd.hist[((size_t)pass * sd.B + b) * 256 + threadIdx.x], v);
+}
+
+__global__ void __launch_bounds__(256)
+proposal_select_kernel(PyramidDev p, long long A_total, const unsigned* __restrict__ fkeys, SelDev sd,
+                       unsigned long long* __restrict__ keys) {
+  __shared__ SelState sh;
+  const int l = blockIdx.y, n = blockIdx.z;
+  const int nl = p.H[l] * p.W[l] * p.A;
+  const int c0 = blockIdx.x * kSelChunk;
+  if (c0 >= nl) return;
+  const int b = n * p.num_levels + l;
+  const SelState st = sel_resolve(sd, b, sd.npass, &sh);
+  const bool split_ties = !st.all && st.remaining < st.eq_count;
   const unsigned goff = (unsigned)p.level_offset[l];
   const unsigned* fk_l = fkeys + (long long)n * A_total + p.level_offset[l];
-  auto keyf = [&](int i, unsigned& kv) -> bool {
-    kv = (~fk_l[i]) & keymask;
-    return true;
-  };
-  SelectResult sel = block_select_threshold(nl, pre_n, nbits, keyf, sm, IdentityIdx(), false);
-  const bool split_ties = sel.mode == 0 && sel.remaining < sel.eq_count;
-  const bool ties_fit = sel.eq_count <= kTieCap;
-  if (split_ties && !ties_fit) {   // rare: resolve the index threshold with the generic global passes
-    sel.IT = block_tie_threshold(nl, sel.remaining, sel.T, keyf, IdentityIdx(), sm);
-  }
-  auto emit = [&](unsigned fk, unsigned i) {
-    int pos = atomicAdd(&n_sel, 1);
-    list[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + i));
-  };
-  for (int i0 = threadIdx.x; i0 < nl; i0 += 4 * blockDim.x) {
-    unsigned fk[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int i = i0 + u * blockDim.x;
-      fk[u] = i < nl ? fk_l[i] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int i = i0 + u * blockDim.x;
-      if (i >= nl) continue;
-      unsigned kv = (~fk[u]) & keymask;
-      if (split_ties && ties_fit) {
-        if (kv < sel.T) emit(fk[u], (unsigned)i);
-        else if (kv == sel.T) ties[atomicAdd(&n_tie, 1)] = (unsigned)i;
-      } else if (sel.chosen(kv, (unsigned)i)) {
-        emit(fk[u], (unsigned)i);
+  unsigned* ties = sd.ties + (long long)n * A_total + p.level_offset[l];
+  unsigned long long* out = keys + (long long)b * sd.pre_n;
+  const int c1 = c0 + kSelChunk < nl ? c0 + kSelChunk : nl;
+  const int lane = threadIdx.x & 63;
+  const int iters = (c1 - c0 + 255) >> 8;   // uniform trip count: whole waves take part in the ballots
+  for (int it = 0; it < iters; ++it) {
+    const int i = c0 + it * 256 + (int)threadIdx.x;
+    const bool in = i < c1;
+    const unsigned fk = in ? fk_l[i] : 0u;
+    const unsigned kv = (~fk) & sd.keymask;
+    const bool take = in && (st.all || kv < st.prefix || (kv == st.prefix && !split_ties));
+    const bool tie = in && split_ties && kv == st.prefix;
+    // one global atomic per wave and list: reserve a run, lanes take consecutive slots
+    unsigned long long mt = __ballot(take), mi = __ballot(tie);
+    if (mt) {
+      int base = 0;
+      if (lane == __ffsll((long long)mt) - 1) base = atomicAdd(&sd.cnt[b * 2 + 0], __popcll(mt));
+      base = __shfl(base, __ffsll((long long)mt) - 1);
+      if (take) {
+        int pos = base + __popcll(mt & ((1ull << lane) - 1ull));
+        out[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
       }
     }
+    if (mi) {
+      int base = 0;
+      if (lane == __ffsll((long long)mi) - 1) base = atomicAdd(&sd.cnt[b * 2 + 1], __popcll(mi));
+      base = __shfl(base, __ffsll((long long)mi) - 1);
+      if (tie) ties[base + __popcll(mi & ((1ull << lane) - 1ull))] = (unsigned)i;
+    }
   }
+}
+
+__global__ void __launch_bounds__(1024)
+proposal_finish_kernel(PyramidDev p, long long A_total, const unsigned* __restrict__ fkeys, SelDev sd, int Kpad,
+                       unsigned long long* __restrict__ keys, int32_t* __restrict__ counts) {
+  __shared__ SelectSmem sm;
+  __shared__ SelState sh;
+  __shared__ unsigned long long list[kMaxPre];
+  __shared__ int n_sel;
+  const int l = blockIdx.x, n = blockIdx.y;
+  const int b = n * p.num_levels + l;
+  const SelState st = sel_resolve(sd, b, sd.npass, &sh);
+  const bool split_ties = !st.all && st.remaining < st.eq_count;
+  const int got = sd.cnt[b * 2 + 0], n_tie = sd.cnt[b * 2 + 1];
+  unsigned long long* out = keys + (long long)b * sd.pre_n;
+  for (int i = threadIdx.x; i < Kpad; i += blockDim.x) list[i] = i < got ? out[i] : 0ull;
+  if (threadIdx.x == 0) n_sel = got;
   __syncthreads();
-  if (split_ties && ties_fit) {
-    // the `remaining` smallest indices of the tie list (every entry has key T: only the index digits matter)
-    const int nt_ = n_tie;
-    auto tkey = [&](int, unsigned& kv) -> bool { kv = sel.T; return true; };
+  if (split_ties) {
+    const unsigned goff = (unsigned)p.level_offset[l];
+    const unsigned* fk_l = fkeys + (long long)n * A_total + p.level_offset[l];
+    const unsigned* ties = sd.ties + (long long)n * A_total + p.level_offset[l];
+    const unsigned T = st.prefix;
+    auto tkey = [&](int, unsigned& kv) -> bool { kv = T; return true; };
     auto tidx = [&](int i) -> unsigned { return ties[i]; };
-    const unsigned IT = block_tie_threshold(nt_, sel.remaining, sel.T, tkey, tidx, sm);
-    for (int j = threadIdx.x; j < nt_; j += blockDim.x) {
+    const unsigned IT = block_tie_threshold(n_tie, st.remaining, T, tkey, tidx, sm);
+    for (int j = threadIdx.x; j < n_tie; j += blockDim.x) {
       unsigned i = ties[j];
-      if (i <= IT) emit(fk_l[i], i);
+      if (i <= IT) {
+        int pos = atomicAdd(&n_sel, 1);
+        list[pos] = ((unsigned long long)fk_l[i] << 32) | (unsigned long long)(0xffffffffu - (goff + i));
+      }
     }
     __syncthreads();
   }
   block_bitonic_sort_desc(list, Kpad);
-  int cnt = n_sel;
-  for (int i = threadIdx.x; i < pre_n; i += blockDim.x) keys[(long long)b * pre_n + i] = list[i];
+  const int cnt = n_sel;
+  for (int i = threadIdx.x; i < sd.pre_n; i += blockDim.x) out[i] = list[i];
   if (threadIdx.x == 0) counts[b] = cnt;
 }
 
@@ -229,6 +347,9 @@ proposal_merge_kernel(int L, int pre_n, int lvl_cap, int post_n,
 
 struct ProposalWs {
   unsigned* fkeys;
+  unsigned* hist;
+  int* cnt;
+  unsigned* ties;
   unsigned long long* keys;
   int32_t* counts;
   float4* boxes;
@@ -250,6 +371,9 @@ static ProposalWs carve(void* base, int B, int pre_n, int N, long long A_total) 
   };
   char* p = (char*)base;
   w.fkeys = (unsigned*)(p + take((size_t)N * A_total * 4));
+  w.hist = (unsigned*)(p + take((size_t)kMaxPasses * B * 256 * 4));
+  w.cnt = (int*)(p + take((size_t)B * 2 * 4));
+  w.ties = (unsigned*)(p + take((size_t)N * A_total * 4));
   w.keys = (unsigned long long*)(p + take((size_t)B * pre_n * 8));
   w.counts = (int32_t*)(p + take((size_t)B * 4));
   w.boxes = (float4*)(p + take((size_t)B * pre_n * 16));
@@ -321,10 +445,24 @@ extern "C" int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* 
   int Kpad = 1;
   while (Kpad < pre_nms_top_n) Kpad <<= 1;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(proposal_gather_kernel, dim3((unsigned)ceil_div<long long>((long long)N * A_total, 256)),
-                     dim3(256), 0, s, d, N, A_total, w.fkeys);
-  hipLaunchKernelGGL(proposal_topk_kernel, dim3(L, N), dim3(1024), 0, s, d, A_total, (const unsigned*)w.fkeys,
-                     pre_nms_top_n, Kpad, w.keys, w.counts);
+  SelDev sd;
+  sd.hist = w.hist; sd.cnt = w.cnt; sd.ties = w.ties;
+  sd.npass = (p->dtype == MXDET_DTYPE_BF16) ? 2 : 4;
+  sd.keymask = (p->dtype == MXDET_DTYPE_BF16) ? 0xffff0000u : 0xffffffffu;
+  sd.B = B; sd.pre_n = pre_nms_top_n;
+  int max_nl = 0;
+  for (int l = 0; l < L; ++l) max_nl = max_nl > p->H[l] * p->W[l] * p->A ? max_nl : p->H[l] * p->W[l] * p->A;
+  long long gthreads = (long long)N * A_total;
+  if (gthreads < (long long)kMaxPasses * B * 256) gthreads = (long long)kMaxPasses * B * 256;
+  hipLaunchKernelGGL(proposal_gather_kernel, dim3((unsigned)ceil_div<long long>(gthreads, 256)), dim3(256), 0, s, d,
+                     N, A_total, w.fkeys, sd);
+  const dim3 sel_grid(ceil_div(max_nl, kSelChunk), L, N);
+  for (int ps = 0; ps < sd.npass; ++ps)
+    hipLaunchKernelGGL(proposal_hist_kernel, sel_grid, dim3(256), 0, s, d, A_total, (const unsigned*)w.fkeys, sd, ps);
+  hipLaunchKernelGGL(proposal_select_kernel, sel_grid, dim3(256), 0, s, d, A_total, (const unsigned*)w.fkeys, sd,
+                     w.keys);
+  hipLaunchKernelGGL(proposal_finish_kernel, dim3(L, N), dim3(1024), 0, s, d, A_total, (const unsigned*)w.fkeys, sd,
+                     Kpad, w.keys, w.counts);
   int tot = B * pre_nms_top_n;
   hipLaunchKernelGGL(proposal_decode_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, s, d, N,
                      pre_nms_top_n, im_info, min_size, w.keys, w.counts, w.boxes, w.invalid);

@@ -441,9 +441,9 @@ extern "C" int mxdet_anchor_target(const float* anchors, int64_t A_total, const 
   hipStream_t s = as_stream(stream);
   int32_t* amax = matched_gt ? matched_gt : w.argmax;
   float* miou = max_iou ? max_iou : w.max_iou;
-  hipError_t e = hipMemsetAsync(w.gt_max, 0, (size_t)N * G_max * 4, s);
+  hipError_t e = zero_async(w.gt_max, (size_t)N * G_max * 4, s);
   MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "anchor_target: memset failed");
-  e = hipMemsetAsync(w.cand.count, 0, w.cand_count_bytes, s);
+  e = zero_async(w.cand.count, w.cand_count_bytes, s);
   MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "anchor_target: memset failed");
   CandLists cl = w.cand;
   if (batch_size <= 0) cl.count = nullptr;   // no sampling: no candidate lists

@@ -83,8 +83,10 @@ class FasterRCNN(DetectorBase):
         self.rpn_head.forward(P)
         # The RPN training branch (anchor targets, RPN losses, RPN head backward: MFMA-heavy) depends only on the
         # head outputs; the proposal -> RoI -> box-head chain (long, low-occupancy selection/NMS kernels) does not
-        # depend on it. They run on two streams and meet at dP. The chain is issued first: it is the longer one.
-        fork_point = self._mark_fork()
+        # depend on it. They run on two streams and meet at dP.
+        with self._branch_ctx():
+            rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset, step_dev=step_dev)
+            self.rpn_head.backward(self.dP, [False] * 5)
         rois, _, _, num_rois = self.rpn_head.get_proposals(im_info)
         rois_s = self.bbox_head.sample(rois, num_rois, gt_boxes, step, image_offset, step_dev)
         pooled = self.roi_extractor.forward(P, rois_s)
@@ -104,9 +106,6 @@ class FasterRCNN(DetectorBase):
         acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
         if self.with_mask:
             self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=False)
-        with self._fork_branch(fork_point):
-            rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset, step_dev=step_dev)
-            self.rpn_head.backward(self.dP, [False] * 5)
         self._join_branch()
         self.roi_extractor.finalize(self.dP[:4], accumulate=True)     # dP[l] = RPN part + RoI part
         self._reduce(0, self.mark_rpn)

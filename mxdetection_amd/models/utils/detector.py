@@ -68,30 +68,52 @@ class DetectorBase:
     def enable_branch_stream(self):
         """Run the RPN training branch on its own stream, concurrently with the proposal / RoI-head chain."""
         self.branch = torch.cuda.Stream()
-        self._branch_anchor = torch.zeros((1,), dtype=torch.int32, device=self.device)
 
-    def _mark_fork(self):
-        """Fork the branch stream from the current point of the main stream. A one-element fill is issued on the branch
-        right away: under hipGraph replay a forked chain starts no earlier than its FIRST node's position in capture
-        order (measured: a branch whose first kernel was captured after the other chain simply ran after it), so the
-        branch is anchored here and the work issued later on it follows that anchor in stream order."""
+    @contextlib.contextmanager
+    def _branch_ctx(self):
+        """Run the body on the branch stream, concurrently with what the caller issues next on the main stream, until
+        _join_branch(). Under capture the body becomes a hipGraph of its own, replayed on the branch stream: two chains
+        forked INSIDE one hipGraph did not overlap on this runtime (the second chain's first kernel started about a
+        millisecond after the fork, whatever the capture order -- profiles/r01_f_fork_inside_graph.txt), while separate
+        graph launches on two streams are at least plain stream semantics. (Measured afterwards: the second chain still
+        starts late whenever the first one is running kernels with more workgroups than the chip holds -- the
+        dispatcher drains a grid before it serves another queue -- so the gain over the in-graph fork is small; what
+        the split did uncover is that memset NODES at the root of a graph do not order against the kernels behind
+        them, hence zero_async() in csrc/common.h.)"""
         if self.branch is None:
-            return None
-        self.branch.wait_stream(torch.cuda.current_stream())
+            yield
+            return
+        cur = torch.cuda.current_stream()
+        if not self._cap:
+            self.branch.wait_stream(cur)
+            with torch.cuda.stream(self.branch):
+                yield
+            return
+        self.ws.join()
+        self._seg_end()
+        self.segments.append(("fork",))
+        g = torch.cuda.CUDAGraph()
+        self.branch.wait_stream(cur)
         with torch.cuda.stream(self.branch):
-            self._branch_anchor.zero_()
-        return True
-
-    def _fork_branch(self, fork_point=None):
-        if self.branch is None:
-            return contextlib.nullcontext()
-        if fork_point is None:
-            self.branch.wait_stream(torch.cuda.current_stream())
-        return torch.cuda.stream(self.branch)
+            # own memory pool: this graph runs concurrently with the main segments, so temporaries allocated while
+            # capturing it must not share (time-multiplexed) memory with theirs
+            g.capture_begin(pool=self._pool_branch)
+            yield
+            g.capture_end()
+        cur.wait_stream(self.branch)
+        self.segments.append(("branch", g))
+        self._seg_begin()
 
     def _join_branch(self):
-        if self.branch is not None:
+        if self.branch is None:
+            return
+        if not self._cap:
             torch.cuda.current_stream().wait_stream(self.branch)
+            return
+        self.ws.join()            # a segment cannot end with weight-gradient work still forked
+        self._seg_end()
+        self.segments.append(("join",))
+        self._seg_begin()
 
     def enable_data_parallel(self, world_size):
         import torch.distributed as dist
@@ -153,6 +175,7 @@ class DetectorBase:
             self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr, gt_masks=self.static_masks)
         torch.cuda.synchronize()
         self._pool = torch.cuda.graph_pool_handle()
+        self._pool_branch = torch.cuda.graph_pool_handle()
         self.segments = []
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -180,10 +203,20 @@ class DetectorBase:
             if gt_masks is not None:
                 self.static_masks.copy_(gt_masks, non_blocking=True)
         self.step_dev.fill_(step)
+        fork_ev = None
         for seg in self.segments:
             if isinstance(seg, tuple):
                 if seg[0] == "reduce":
                     self.reducer.reduce(seg[1], seg[2])
+                elif seg[0] == "fork":
+                    fork_ev = torch.cuda.Event()
+                    fork_ev.record()
+                elif seg[0] == "branch":
+                    self.branch.wait_event(fork_ev)
+                    with torch.cuda.stream(self.branch):
+                        seg[1].replay()
+                elif seg[0] == "join":
+                    torch.cuda.current_stream().wait_stream(self.branch)
                 else:
                     self.reducer.wait()
             else:

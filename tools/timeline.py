@@ -8,11 +8,11 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"),
                      r.get("Queue_Id", "0")))
 rows.sort()
-# a step ends with the sgd kernel; take the window between the last two sgd launches
-sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[2]]
+# a step starts with the stem kernel; take the window between the third- and second-last launches of it
+sgd = [i for i, r in enumerate(rows) if "stem_conv_kernel" in r[2]]
 if len(sgd) < 3:
     sys.exit("need >= 3 steps in the trace")
-lo, hi = sgd[-3] + 1, sgd[-2] + 1
+lo, hi = sgd[-3], sgd[-2]
 win = rows[lo:hi]
 t0, t1 = win[0][0], max(r[1] for r in win)
 print("kernels in step: %d   wall %.3f ms" % (len(win), (t1 - t0) / 1e6))
