@@ -156,6 +156,88 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, const int32_t* __re
   if (lane == 0) num_keep[b] = total < max_keep ? total : max_keep;
 }
 
+// Stage 2 for lists of at most NW*64 boxes (the RPN case: 2000 -> 32 words). Same algorithm as nms_scan_kernel with
+// the global-memory latency taken off the dependent chain: every lane keeps its own box's mask row (words w..nw-1) in
+// registers, and the rows of word w+1 are fetched -- all loads independent, issued back to back -- while word w is
+// being resolved. The OR of a kept box's row into the later `removed` words then reads registers only.
+template <int NW>
+__global__ void __launch_bounds__(64)
+nms_scan_rows_kernel(const unsigned long long* __restrict__ mask, const int32_t* __restrict__ counts,
+                     const uint8_t* __restrict__ invalid, int n_max, int nwords_max, int max_keep,
+                     int32_t* __restrict__ keep_idx, int32_t* __restrict__ num_keep) {
+  __shared__ unsigned long long rem[NW];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int n = counts[b];
+  n = n > n_max ? n_max : n;
+  n = __builtin_amdgcn_readfirstlane(n);
+  const int nw = (n + 63) >> 6;
+  const unsigned long long* m = mask + (int64_t)b * n_max * nwords_max;
+  for (int w = 0; w < nw; ++w) {
+    int idx = w * 64 + lane;
+    bool bad = (idx >= n) || (invalid != nullptr && invalid[(int64_t)b * n_max + idx] != 0);
+    unsigned long long bm = __ballot(bad);
+    if (lane == 0) rem[w] = bm;
+  }
+  __syncthreads();
+  unsigned long long cur[NW], nxt[NW];
+  auto load_row = [&](unsigned long long (&r)[NW], int w) {   // words w..nw-1 of box w*64+lane (upper triangle only)
+    const int row = w * 64 + lane;
+    const unsigned long long* rp = m + (int64_t)row * nwords_max;
+#pragma unroll
+#ifdef NMS_ABL_NOLOAD
+    for (int j = 0; j < NW; ++j) r[j] = (j == w && row < n) ? rp[j] : 0ull;
+#else
+    for (int j = 0; j < NW; ++j) r[j] = (j >= w && j < nw && row < n) ? rp[j] : 0ull;
+#endif
+  };
+  load_row(cur, 0);
+  unsigned long long mykeep = 0;
+  for (int w = 0; w < nw; ++w) {
+    if (w + 1 < nw) load_row(nxt, w + 1);
+    unsigned long long diag = 0ull;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) diag = (j == w) ? cur[j] : diag;
+    __syncthreads();   // the LDS atomics of the previous words have landed (one wave: a cheap s_barrier)
+    // Box bb of this word is kept iff bit bb of `c` is clear when its turn comes; a diagonal row only has bits above
+    // its own index, so bit bb never changes afterwards and the keep mask is simply ~c at the end: the dependent
+    // chain per box is readlane -> select -> or.
+    unsigned long long c = readlane64(rem[w], 0);
+#pragma unroll
+    for (int bb = 0; bb < 64; ++bb) {
+      unsigned long long d = readlane64(diag, bb);
+      c |= ((c >> bb) & 1ull) ? 0ull : d;
+    }
+    const unsigned long long keepbits = ~c;
+    if (lane == w) mykeep = keepbits;
+#ifndef NMS_ABL_NOOR
+    if ((keepbits >> lane) & 1ull) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+        if (j > w && j < nw && cur[j]) atomicOr(&rem[j], cur[j]);
+    }
+#endif
+#pragma unroll
+    for (int j = 0; j < NW; ++j) cur[j] = nxt[j];
+  }
+  int cnt = __popcll(mykeep);
+  int incl = cnt;
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  int excl = incl - cnt;
+  int total = __shfl(incl, 63);
+  unsigned long long kb = mykeep;
+  int pos = excl;
+  while (kb) {
+    int bb = __ffsll((long long)kb) - 1;
+    kb &= kb - 1;
+    if (pos < max_keep) keep_idx[(int64_t)b * n_max + pos] = lane * 64 + bb;
+    ++pos;
+  }
+  if (lane == 0) num_keep[b] = total < max_keep ? total : max_keep;
+}
+
 }  // namespace mxdet
 
 using namespace mxdet;
@@ -223,8 +305,13 @@ extern "C" int mxdet_nms_batched(const float* boxes, const int32_t* counts, cons
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, B), dim3(64), 0, as_stream(stream),
                      (const float4*)boxes, counts, n_max, nwords, thresh,
                      (unsigned long long*)workspace);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, as_stream(stream),
-                     (const unsigned long long*)workspace, counts, invalid, n_max, nwords,
-                     max_keep < 0 ? 0 : max_keep, keep_idx, num_keep);
+  if (nwords <= 32)
+    hipLaunchKernelGGL(nms_scan_rows_kernel<32>, dim3(B), dim3(64), 0, as_stream(stream),
+                       (const unsigned long long*)workspace, counts, invalid, n_max, nwords,
+                       max_keep < 0 ? 0 : max_keep, keep_idx, num_keep);
+  else
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, as_stream(stream),
+                       (const unsigned long long*)workspace, counts, invalid, n_max, nwords,
+                       max_keep < 0 ? 0 : max_keep, keep_idx, num_keep);
   return check_launch("nms_batched");
 }

@@ -174,33 +174,30 @@ proposal_select_kernel(PyramidDev p, long long A_total, const unsigned* __restri
   unsigned* ties = sd.ties + (long long)n * A_total + p.level_offset[l];
   unsigned long long* out = keys + (long long)b * sd.pre_n;
   const int c1 = c0 + kSelChunk < nl ? c0 + kSelChunk : nl;
-  const int lane = threadIdx.x & 63;
-  const int iters = (c1 - c0 + 255) >> 8;   // uniform trip count: whole waves take part in the ballots
-  for (int it = 0; it < iters; ++it) {
-    const int i = c0 + it * 256 + (int)threadIdx.x;
-    const bool in = i < c1;
-    const unsigned fk = in ? fk_l[i] : 0u;
+  // Chosen keys / tie indices of this chunk are first collected in LDS (LDS atomics), then ONE global atomic per
+  // workgroup and list reserves the output run: same-address global atomics from every wave of the grid serialise
+  // at the L2 and were most of this kernel's time.
+  __shared__ unsigned long long s_take[kSelChunk];
+  __shared__ unsigned s_tie[kSelChunk];
+  __shared__ int s_nt, s_ni, s_bt, s_bi;
+  if (threadIdx.x == 0) { s_nt = 0; s_ni = 0; }
+  __syncthreads();
+  for (int i = c0 + (int)threadIdx.x; i < c1; i += 256) {
+    const unsigned fk = fk_l[i];
     const unsigned kv = (~fk) & sd.keymask;
-    const bool take = in && (st.all || kv < st.prefix || (kv == st.prefix && !split_ties));
-    const bool tie = in && split_ties && kv == st.prefix;
-    // one global atomic per wave and list: reserve a run, lanes take consecutive slots
-    unsigned long long mt = __ballot(take), mi = __ballot(tie);
-    if (mt) {
-      int base = 0;
-      if (lane == __ffsll((long long)mt) - 1) base = atomicAdd(&sd.cnt[b * 2 + 0], __popcll(mt));
-      base = __shfl(base, __ffsll((long long)mt) - 1);
-      if (take) {
-        int pos = base + __popcll(mt & ((1ull << lane) - 1ull));
-        out[pos] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
-      }
-    }
-    if (mi) {
-      int base = 0;
-      if (lane == __ffsll((long long)mi) - 1) base = atomicAdd(&sd.cnt[b * 2 + 1], __popcll(mi));
-      base = __shfl(base, __ffsll((long long)mi) - 1);
-      if (tie) ties[base + __popcll(mi & ((1ull << lane) - 1ull))] = (unsigned)i;
-    }
+    if (st.all || kv < st.prefix || (kv == st.prefix && !split_ties))
+      s_take[atomicAdd(&s_nt, 1)] = ((unsigned long long)fk << 32) | (unsigned long long)(0xffffffffu - (goff + (unsigned)i));
+    else if (split_ties && kv == st.prefix)
+      s_tie[atomicAdd(&s_ni, 1)] = (unsigned)i;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_bt = s_nt ? atomicAdd(&sd.cnt[b * 2 + 0], s_nt) : 0;
+    s_bi = s_ni ? atomicAdd(&sd.cnt[b * 2 + 1], s_ni) : 0;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < s_nt; j += 256) out[s_bt + j] = s_take[j];
+  for (int j = threadIdx.x; j < s_ni; j += 256) ties[s_bi + j] = s_tie[j];
 }
 
 __global__ void __launch_bounds__(1024)

@@ -60,27 +60,41 @@ struct CandLists {
   int* idx;        // [N][2][kCandCap]
   int* count;      // [N][4]: appended fg, appended bg, total fg, total bg
 };
-// Wave-aggregated append: one atomic per wave and stream. Must be called by every lane of the wave
-// (lab < 0 = nothing to append). count[n*4+0] ends up as the number of ALL foreground anchors, count[n*4+1] as
-// the number of background anchors below the key cut (both may exceed kCandCap: then the list is incomplete).
+// Workgroup-aggregated append: ONE global atomic per workgroup and stream (every wave of the grid hitting the same
+// counter costs ~5 ns each at the L2: 17k waves made this kernel 90 us). Waves count with a ballot, the counts
+// meet in LDS, the first thread reserves the workgroup's run, lanes take consecutive slots. Must be called by
+// every thread of a 256-thread workgroup (lab < 0 = nothing to append); contains two barriers. count[n*4+0] ends up
+// as the number of ALL foreground anchors, count[n*4+1] as the number of background anchors below the key cut (both
+// may exceed kCandCap: then the list is incomplete). The order of a list does not matter to the sampler.
 __device__ __forceinline__ void cand_append(const CandLists& c, int n, int lab, unsigned key, int a) {
+  __shared__ int s_cnt[2][4];
+  __shared__ int s_base[2];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  bool want[2];
+  unsigned long long m[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    const bool want = (st == 0) ? (lab == 1) : (lab == 0 && key < kBgKeyCut);
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull) continue;
-    const int lane = lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&c.count[n * 4 + st], __popcll(m));
-    base = __shfl(base, leader);
-    if (want) {
-      const unsigned long long below = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
-      const int pos = base + __popcll(below);
-      if (pos < kCandCap) {
-        c.key[((long long)n * 2 + st) * kCandCap + pos] = key;
-        c.idx[((long long)n * 2 + st) * kCandCap + pos] = a;
-      }
+    want[st] = (st == 0) ? (lab == 1) : (lab == 0 && key < kBgKeyCut);
+    m[st] = __ballot(want[st]);
+    if (lane == 0) s_cnt[st][wv] = __popcll(m[st]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int st = threadIdx.x;
+    const int tot = s_cnt[st][0] + s_cnt[st][1] + s_cnt[st][2] + s_cnt[st][3];
+    s_base[st] = tot ? atomicAdd(&c.count[n * 4 + st], tot) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    if (!want[st]) continue;
+    int base = s_base[st];
+    for (int k = 0; k < wv; ++k) base += s_cnt[st][k];
+    const unsigned long long below = (lane == 0) ? 0ull : (m[st] & (~0ull >> (64 - lane)));
+    const int pos = base + __popcll(below);
+    if (pos < kCandCap) {
+      c.key[((long long)n * 2 + st) * kCandCap + pos] = key;
+      c.idx[((long long)n * 2 + st) * kCandCap + pos] = a;
     }
   }
 }
@@ -122,7 +136,7 @@ anchor_label_kernel(const float4* __restrict__ anchors, long long A_total, const
     labels[(long long)n * A_total + a] = lab;
     keys[(long long)n * A_total + a] = key;
   }
-  if (cand.count != nullptr) cand_append(cand, n, lab, key, (int)a);   // wave-uniform call
+  if (cand.count != nullptr) cand_append(cand, n, lab, key, (int)a);   // workgroup-uniform call
 }
 
 // An inside anchor of an image with no valid GT has max_iou = -1 above; the lineage labels those
