@@ -35,6 +35,12 @@ def run():
 for _ in range(3):
     run()
 torch.cuda.synchronize()
+if os.environ.get("MXDET_EAGER_TIMING"):   # counter collection wants plain dispatches, not graph replays
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    print("%s eager x%d done" % (kind, reps))
+    sys.exit(0)
 # device time only: reps launches inside one hipGraph (a small conv is shorter than a ctypes call)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
