@@ -36,6 +36,10 @@ struct ConvP {
   int relu, res_up;
   int M;
   int tiles_m, tiles_n;
+  // stride-2 data gradient, parity-grouped rows (PAR): class c = 2*ph + pw with ph = (hd+pad)&1, pw = (wd+pad)&1
+  int par_tile0[5];          // first m-tile of each class (prefix sums), [4] = total
+  int par_hc[2], par_wc[2];  // number of rows / columns of each parity
+  int par_h0[2], par_w0[2];  // first coordinate of each parity
   int m_begin;     // first output row of this launch (a layer may be covered by two launches with different tiles)
   int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
 };
@@ -56,7 +60,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // NS-1 stages (48-96 KiB per CU) are in flight and the global-load latency is off the critical path.
 // One counted s_waitcnt vmcnt + one raw s_barrier per K-step; the LDS image is lane-linear, so the
 // conflict-avoiding XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read side.
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -82,12 +86,30 @@ conv_igemm_kernel(ConvP p) {
   // tiles share their A rows (n fastest), so the A tile is re-read from that XCD's L2.
   int bid = blockIdx.x;
   const int nwg = gridDim.x;
-  {
+  if constexpr (!PAR) {   // PAR: classes differ 4:2:2:1 in work and are laid out one after the other -- giving each XCD
+                          // a contiguous range would put all the heavy tiles on two of the eight; keep the hardware's
+                          // round-robin instead
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
+  int m0 = p.m_begin + tile_m * BM;
+  const int n0 = tile_n * BN;
+  // PAR (stride-2 data gradient): rows are grouped by the parity class of (hd+pad, wd+pad). Inside a class every
+  // row has the same set of filter taps that land on a source pixel -- (KH-ph+1)/2 x (KW-pw+1)/2 of them, 9 over
+  // the four classes of a 3x3 instead of 36 -- so the K loop runs over exactly those taps (none at all for three
+  // of the four classes of a 1x1/2 shortcut: such tiles go straight to the epilogue).
+  int par_ph = 0, par_pw = 0, par_rows = 0, par_hc = 1, par_wc = 1, nkh = p.KH, nkw = p.KW;
+  if constexpr (PAR) {
+    int c = 0;
+    while (c < 3 && tile_m >= p.par_tile0[c + 1]) ++c;
+    par_ph = c >> 1; par_pw = c & 1;
+    par_hc = p.par_hc[par_ph]; par_wc = p.par_wc[par_pw];
+    par_rows = p.N * par_hc * par_wc;
+    m0 = (tile_m - p.par_tile0[c]) * BM;            // row index inside the class
+    nkh = (p.KH - par_ph + 1) >> 1; nkw = (p.KW - par_pw + 1) >> 1;
+    nkh = nkh < 0 ? 0 : nkh; nkw = nkw < 0 ? 0 : nkw;
+  }
 
   // ---- per-lane gather geometry: lane l of DMA instruction j fills row 8j + (l>>3), 16-B slot l&7 -------
   // The address math is hoisted out of the K loop (the loop was VALU-issue bound on it): per row a base
@@ -105,6 +127,22 @@ conv_igemm_kernel(ConvP p) {
     int coff = (lslot ^ ((ra >> 1) & 7)) << 3;
     unsigned mask = 0;
     int off = 0;
+    if constexpr (PAR) {
+      if (m < par_rows) {
+        int img = m / (par_hc * par_wc);
+        int rem = m - img * (par_hc * par_wc);
+        int ih = rem / par_wc, iw = rem - ih * par_wc;
+        int hd = p.par_h0[par_ph] + 2 * ih, wd = p.par_w0[par_pw] + 2 * iw;
+        // first valid tap is (kh, kw) = (ph, pw); tap (ph + 2a, pw + 2b) reads source (hs0 - a, ws0 - b)
+        int hs0 = (hd + p.pad - par_ph) >> 1, ws0 = (wd + p.pad - par_pw) >> 1;
+        off = ((img * p.Hs + hs0) * p.Ws + ws0) * p.C + coff;
+        for (int a = 0; a < nkh; ++a)
+          for (int b = 0; b < nkw; ++b) {
+            int hs = hs0 - a, ws = ws0 - b;
+            if (hs >= 0 && ws >= 0 && hs < p.Hs && ws < p.Ws) mask |= 1u << (a * nkw + b);
+          }
+      }
+    } else
     if (m < p.M) {
       int img = m / (p.Hd * p.Wd);
       int rem = m - img * (p.Hd * p.Wd);
@@ -131,7 +169,7 @@ conv_igemm_kernel(ConvP p) {
     a_mask[i] = mask;
   }
   const int Ktot = ntaps * p.C;
-  const int KT = Ktot >> 6;
+  const int KT = PAR ? (nkh * nkw * p.C) >> 6 : Ktot >> 6;
   const uint16_t* wrow[GB];
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
@@ -146,11 +184,17 @@ conv_igemm_kernel(ConvP p) {
   auto issue_stage = [&](int buf) {
     unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
     const bool live = ld_kt < KT;
-    const int tap = live ? ld_kh * p.KW + ld_kw : 31;                  // bit 31 is never set in a_mask
-    int delta;                                                         // uniform displacement of this tap
-    if (DGRAD) delta = ld_c0 - ((ld_kh / p.stride) * p.Ws + (ld_kw / p.stride)) * p.C;
-    else delta = ld_c0 + (ld_kh * p.Ws + ld_kw) * p.C;
-    const int koff = live ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;  // column of (tap, slice) in the filter rows
+    int tap, delta, koff;   // bit of a_mask, uniform displacement of this tap, column of (tap, slice) in the filter rows
+    if constexpr (PAR) {
+      tap = live ? ld_kh * nkw + ld_kw : 31;                           // bit 31 is never set in a_mask
+      delta = ld_c0 - (ld_kh * p.Ws + ld_kw) * p.C;
+      koff = live ? ((par_ph + 2 * ld_kh) * p.KW + (par_pw + 2 * ld_kw)) * p.C + ld_c0 : 0;
+    } else {
+      tap = live ? ld_kh * p.KW + ld_kw : 31;
+      if (DGRAD) delta = ld_c0 - ((ld_kh / p.stride) * p.Ws + (ld_kw / p.stride)) * p.C;
+      else delta = ld_c0 + (ld_kh * p.Ws + ld_kw) * p.C;
+      koff = live ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;
+    }
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
       const unsigned short* src = ((a_mask[i] >> tap) & 1u) ? p.x + (a_off[i] + delta) : zero;
@@ -178,9 +222,9 @@ conv_igemm_kernel(ConvP p) {
     // K order = (channel slice, kh, kw) with the TAP fastest: the KH*KW shifted re-reads of one 128-B
     // activation chunk happen in consecutive steps, while that chunk is still in this XCD's L2
     ++ld_kt;
-    if (++ld_kw == p.KW) {
+    if (++ld_kw == nkw) {
       ld_kw = 0;
-      if (++ld_kh == p.KH) { ld_kh = 0; ld_c0 += 64; }
+      if (++ld_kh == nkh) { ld_kh = 0; ld_c0 += 64; }
     }
   };
 
@@ -272,7 +316,16 @@ conv_igemm_kernel(ConvP p) {
       int col = n0 + wn * WTN + cg * 8;
       float4 v0 = *(const float4*)(ep + row * EP_STRIDE + cg * 8);
       float4 v1 = *(const float4*)(ep + row * EP_STRIDE + cg * 8 + 4);
-      if (m < p.M && col < p.Ncols) {
+      bool rowok = m < p.M;
+      size_t pix = (size_t)m;          // linear output pixel of this row
+      if constexpr (PAR) {
+        rowok = m < par_rows;
+        int img = m / (par_hc * par_wc);
+        int rem = m - img * (par_hc * par_wc);
+        int ih = rem / par_wc, iw = rem - ih * par_wc;
+        pix = (size_t)(img * p.Hd + p.par_h0[par_ph] + 2 * ih) * p.Wd + (p.par_w0[par_pw] + 2 * iw);
+      }
+      if (rowok && col < p.Ncols) {
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (p.bias) {
           float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
@@ -288,7 +341,7 @@ conv_igemm_kernel(ConvP p) {
             int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
             ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * p.Ncols + col;
           } else {
-            ri = (size_t)m * p.Ncols + col;
+            ri = pix * p.Ncols + col;
           }
           uint4 rv = *(const uint4*)(p.res + ri);
           v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
@@ -297,7 +350,7 @@ conv_igemm_kernel(ConvP p) {
           v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
         }
         if (p.mask) {
-          uint4 mv = *(const uint4*)(p.mask + (size_t)m * p.Ncols + col);
+          uint4 mv = *(const uint4*)(p.mask + pix * p.Ncols + col);
           // bf16 > 0  <=>  sign clear and magnitude non-zero
           unsigned mm[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
@@ -316,7 +369,7 @@ conv_igemm_kernel(ConvP p) {
         o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
         o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
         o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
-        *(uint4*)(p.y + (size_t)m * p.Ncols + col) = o;
+        *(uint4*)(p.y + pix * p.Ncols + col) = o;
       }
     }
   }
@@ -324,12 +377,21 @@ conv_igemm_kernel(ConvP p) {
 
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
 static int launch_cfg(ConvP& p, hipStream_t s) {
+  if (PAR) {   // rows grouped by parity class: tiles never straddle two classes
+    int t = 0;
+    for (int c = 0; c < 4; ++c) {
+      p.par_tile0[c] = t;
+      t += ceil_div(p.N * p.par_hc[c >> 1] * p.par_wc[c & 1], BM);
+    }
+    p.par_tile0[4] = t;
+    p.tiles_m = t;
+  }
   if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);   // caller may restrict the row range
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD>), dim3((unsigned)nwg), dim3(64 * WM * WN),
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR>), dim3((unsigned)nwg), dim3(64 * WM * WN),
                      0, s, p);
   return check_launch("conv2d");
 }
@@ -361,6 +423,21 @@ static int launch(ConvP& p, hipStream_t s) {
     case 16: return launch_cfg<256, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 64x64 per wave, 96 KiB
     case 17: return launch_cfg<256, 128, 2, 2, 2, DGRAD>(p, s);   // 4 waves, 128x64 per wave, 96 KiB
     default: break;
+  }
+  if constexpr (DGRAD) {
+    if (p.stride == 2 && force == 0) {
+      // stride-2 data gradient: parity-grouped rows, only the taps that exist (a quarter of the MACs)
+      for (int par = 0; par < 2; ++par) {
+        // coordinates hd in [0,Hd) with (hd + pad) & 1 == par
+        int h0 = ((par - p.pad) % 2 + 2) % 2, w0 = h0;
+        p.par_h0[par] = h0; p.par_w0[par] = w0;
+        p.par_hc[par] = p.Hd > h0 ? (p.Hd - h0 + 1) / 2 : 0;
+        p.par_wc[par] = p.Wd > w0 ? (p.Wd - w0 + 1) / 2 : 0;
+      }
+      if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, true, true>(p, s);
+      if (t64 >= 1600) return launch_cfg<64, 128, 2, 2, 2, true, true>(p, s);
+      return launch_cfg<64, 64, 2, 2, 3, true, true>(p, s);
+    }
   }
   if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
   if (t128 >= 1536 && K > 256) {
