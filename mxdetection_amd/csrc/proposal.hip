@@ -77,44 +77,14 @@ struct SelState {
   int remaining, eq_count, all;   // all: fewer candidates than requested -> everything is chosen
 };
 
-// first bin b with hist[b] > 0 and cum(b-1) + hist[b] >= remaining; whole wave participates
-__device__ inline void wave_find_bin(const unsigned* __restrict__ hist, int remaining, int* bin, int* cum_before,
-                                     int* bin_count) {
-  const int lane = threadIdx.x & 63;
-  uint4 v = *(const uint4*)(hist + lane * 4);
-  int c[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-  int s = c[0] + c[1] + c[2] + c[3];
-  int incl = s;
-  for (int off = 1; off < 64; off <<= 1) {
-    int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  int excl = incl - s;
-  // lanes whose range contains the crossing: excl < remaining' <= incl  (remaining' = max(remaining,1))
-  int need = remaining > 1 ? remaining : 1;
-  bool here = s > 0 && excl < need && incl >= need;
-  unsigned long long m = __ballot(here);
-  if (m == 0ull) { *bin = 256; *cum_before = incl; *bin_count = 0; return; }
-  int src = __ffsll((long long)m) - 1;
-  int b = 0, cb = excl, bc = 0;
-  if (lane == src) {
-    int cum = excl;
-    for (int j = 0; j < 4; ++j) {
-      if (c[j] > 0 && cum + c[j] >= need) { b = lane * 4 + j; cb = cum; bc = c[j]; break; }
-      cum += c[j];
-    }
-  }
-  *bin = __shfl(b, src); *cum_before = __shfl(cb, src); *bin_count = __shfl(bc, src);
-}
-
 __device__ inline SelState sel_resolve(const SelDev& sd, int b, int npass_done, SelState* sh) {
   if (threadIdx.x < 64) {
     SelState st;
     st.prefix = 0; st.mask = 0; st.remaining = sd.pre_n; st.eq_count = 0; st.all = 0;
     for (int ps = 0; ps < npass_done && !st.all; ++ps) {
       const int shift = 24 - 8 * ps;
-      int bin, cum, bc;
-      wave_find_bin(sd.hist + ((size_t)ps * sd.B + b) * 256, st.remaining, &bin, &cum, &bc);
+      int bin, cum, bc, tot;
+      wave_scan_bins(sd.hist + ((size_t)ps * sd.B + b) * 256, st.remaining, &bin, &cum, &bc, &tot);
       if (bin == 256) { st.all = 1; break; }
       st.prefix |= (unsigned)bin << shift;
       st.mask |= 255u << shift;

@@ -14,7 +14,7 @@
 namespace mxdet {
 
 struct SelectSmem {
-  unsigned hist[256];
+  __attribute__((aligned(16))) unsigned hist[256];
   int scratch[32];
   unsigned prefix;
   int remaining;
@@ -40,6 +40,42 @@ __device__ __forceinline__ void hist_add_agg(unsigned* hist, bool ok, unsigned b
     ok = ok && !same;
   }
   if (ok) atomicAdd(&hist[bin], 1u);
+}
+
+// One wave finds the first bin b of a 256-bin histogram with hist[b] > 0 and cum(b-1) + hist[b] >= remaining (the scan
+// a single thread did serially: 256 dependent LDS reads per radix pass). Lane l owns bins 4l..4l+3; returns through
+// the wave (all 64 lanes must call): bin (256 = none: fewer candidates than requested), candidates before it, its
+// count, and the histogram total.
+__device__ __forceinline__ void wave_scan_bins(const unsigned* hist, int remaining, int* bin, int* cum_before,
+                                               int* bin_count, int* total) {
+  const int lane = threadIdx.x & 63;
+  const uint4 v = *(const uint4*)(hist + lane * 4);
+  const int c[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+  const int s = c[0] + c[1] + c[2] + c[3];
+  int incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const int excl = incl - s;
+  *total = __shfl(incl, 63);
+  // the serial rule `cum + c >= remaining && c > 0`: with remaining <= 0 it is the first non-empty bin
+  const int need = remaining > 1 ? remaining : 1;
+  const bool here = s > 0 && excl < need && incl >= need;
+  const unsigned long long m = __ballot(here);
+  if (m == 0ull) { *bin = 256; *cum_before = incl; *bin_count = 0; return; }
+  const int src = __ffsll((long long)m) - 1;
+  int b = 0, cb = 0, bc = 0;
+  if (lane == src) {
+    int cum = excl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (bc == 0 && c[j] > 0 && cum + c[j] >= need) { b = lane * 4 + j; cb = cum; bc = c[j]; }
+      cum += c[j];
+    }
+  }
+  *bin = __shfl(b, src); *cum_before = __shfl(cb, src); *bin_count = __shfl(bc, src);
 }
 
 struct SelectResult {
@@ -80,15 +116,13 @@ __device__ inline unsigned block_tie_threshold(int n, int remaining, unsigned T,
         hist_add_agg(sm.hist, ok[u] && kv[u] == T && (ix[u] & im) == ip, (ix[u] >> shift) & 255u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, b = 0;
-      for (; b < 256; ++b) {
-        int c = (int)sm.hist[b];
-        if (cum + c >= remaining && c > 0) break;
-        cum += c;
+    if (tid < 64) {
+      int b, cum, bc, tot;
+      wave_scan_bins(sm.hist, remaining, &b, &cum, &bc, &tot);
+      if (tid == 0) {
+        sm.prefix = ip | ((unsigned)b << shift);
+        sm.remaining = remaining - cum;
       }
-      sm.prefix = ip | ((unsigned)b << shift);
-      sm.remaining = remaining - cum;
     }
     __syncthreads();
     ip = sm.prefix;
@@ -126,23 +160,19 @@ __device__ inline SelectResult block_select_threshold(int n, int k, int nbits, K
         hist_add_agg(sm.hist, ok[u] && (kv[u] & mask) == prefix, (kv[u] >> shift) & 255u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, b = 0, total = 0;
-      if (first)
-        for (int j = 0; j < 256; ++j) total += (int)sm.hist[j];
-      for (; b < 256; ++b) {
-        int c = (int)sm.hist[b];
-        if (cum + c >= remaining && c > 0) break;
-        cum += c;
-      }
-      if (first) sm.scratch[0] = total;
-      if (b == 256) {
-        sm.flag_all = 1;  // fewer candidates than requested
-      } else {
-        sm.flag_all = 0;
-        sm.prefix = prefix | ((unsigned)b << shift);
-        sm.remaining = remaining - cum;
-        sm.bin_count = (int)sm.hist[b];
+    if (tid < 64) {
+      int b, cum, bc, total;
+      wave_scan_bins(sm.hist, remaining, &b, &cum, &bc, &total);
+      if (tid == 0) {
+        if (first) sm.scratch[0] = total;
+        if (b == 256) {
+          sm.flag_all = 1;  // fewer candidates than requested
+        } else {
+          sm.flag_all = 0;
+          sm.prefix = prefix | ((unsigned)b << shift);
+          sm.remaining = remaining - cum;
+          sm.bin_count = bc;
+        }
       }
     }
     __syncthreads();

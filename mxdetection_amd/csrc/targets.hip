@@ -347,11 +347,8 @@ proposal_target_kernel(const float* __restrict__ rois, const int32_t* __restrict
   float* otgt = bbox_targets + (long long)n * R * reg_dim;
   float* owgt = bbox_weights + (long long)n * R * reg_dim;
   int32_t* omg = matched_gt + (long long)n * R;
-  // zero-fill targets / weights and the padding slots
-  for (long long i = threadIdx.x; i < (long long)R * reg_dim; i += blockDim.x) {
-    otgt[i] = 0.0f;
-    owgt[i] = 0.0f;
-  }
+  // targets / weights were zero-filled by a chip-wide kernel before this launch (1.3 MB per image is far too much
+  // for one workgroup); here only the padding slots
   for (int s = nfg + nbg + threadIdx.x; s < R; s += blockDim.x) {
     float* r = orois + (long long)s * 5;
     r[0] = (float)n; r[1] = 0.f; r[2] = 0.f; r[3] = 0.f; r[4] = 0.f;
@@ -509,6 +506,13 @@ extern "C" int mxdet_proposal_target(const float* rois, const int32_t* num_rois,
   // means/stds are tiny host arrays by contract (passed by value into the kernel)
   float4 m = make_float4(means[0], means[1], means[2], means[3]);
   float4 sd = make_float4(stds[0], stds[1], stds[2], stds[3]);
+  {
+    const size_t reg_dim = class_agnostic ? 4 : 4 * (size_t)num_classes;
+    const size_t bytes = (size_t)N * rois_per_image * reg_dim * sizeof(float);
+    hipError_t e = zero_async(bbox_targets, bytes, as_stream(stream));
+    if (e == hipSuccess) e = zero_async(bbox_weights, bytes, as_stream(stream));
+    MXDET_REQUIRE(e == hipSuccess, MXDET_EHIP, "proposal_target: zero fill failed");
+  }
   hipLaunchKernelGGL(proposal_target_kernel, dim3(N), dim3(1024), lds, as_stream(stream), rois,
                      num_rois, rois_stride, gt_boxes, G_max, rois_per_image, max_fg, fg_thresh, bg_hi,
                      bg_lo, num_classes, class_agnostic, m, sd, seed, step, step_dev, image_offset, out_rois,
