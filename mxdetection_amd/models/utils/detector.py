@@ -25,6 +25,11 @@ class DetectorBase:
         self._upd = None          # (lr, momentum, wd) while a training step wants its buckets updated as they finish
         self._upd_done = []       # arena ranges already updated in this step
         self._tr_ranges = {}
+        self._buckets = []        # (lo, hi) of every bucket exchanged in the captured step
+        self._seen_buckets = set()
+        self._final_join_opt = False
+        self._cap_opt = None      # (lr, momentum, wd) while capturing per-bucket update graphs (N > 1)
+        self.opt_stream = None
 
     def _finalize_params(self, layers, frozen_layers=()):
         self.layers = layers
@@ -126,10 +131,27 @@ class DetectorBase:
         if self._cap:
             if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
                 self._seg_end()
-                self.segments.append(("reduce", lo, hi))
+                k = len(self._buckets)
+                self._buckets.append((lo, hi))
+                self.segments.append(("reduce", lo, hi, k))
+                if self._cap_opt is not None:
+                    # The bucket's update is a small graph of its own, replayed on the optimizer stream once that
+                    # stream has waited for the bucket's all-reduce: it overlaps the rest of backward exactly like
+                    # the single-GPU path, and the main stream never waits for a collective before the end of the step.
+                    g = torch.cuda.CUDAGraph()
+                    cur = torch.cuda.current_stream()
+                    self.opt_stream.wait_stream(cur)
+                    with torch.cuda.stream(self.opt_stream):
+                        g.capture_begin(pool=self._pool_opt)
+                        self._apply_update(lo, hi, self._cap_opt, 1.0 / self.world)
+                        g.capture_end()
+                    cur.wait_stream(self.opt_stream)
+                    self.segments.append(("update", g, k))
                 self._seg_begin()
         else:
             self.reducer.reduce(lo, hi)
+            if hi > lo:
+                self._seen_buckets.add((lo, hi))
         if self._upd is not None and self.dist is None and hi > lo:
             self._update_range(lo, hi)
 
@@ -138,19 +160,29 @@ class DetectorBase:
         nothing issued so far in this step reads these parameters any more, so the update overlaps the rest of the
         backward pass instead of forming a serial tail after it (single-GPU path; with a gradient exchange the update
         follows the last all-reduce, see optimizer_step)."""
-        from ...ops import dense
-        lr, momentum, wd = self._upd
-        a = self.arena
         ctx = self.ws.fork()
         with (ctx if ctx is not None else contextlib.nullcontext()):
-            dense.sgd_momentum_update(a.w[lo:hi], a.g[lo:hi], a.m[lo:hi], a.wb[lo:hi], lr, momentum, wd, 1.0)
-            key = (lo, hi)
-            if key not in self._tr_ranges:
-                pairs = [(l.w_bf16, l.wt) for l in self.layers if l.trainable and lo <= a.offset_of(l.wi) < hi]
-                self._tr_ranges[key] = dense.make_transpose_table(pairs, self.device) if pairs else None
-            if self._tr_ranges[key] is not None:
-                dense.filter_transpose_batched(*self._tr_ranges[key])
+            self._apply_update(lo, hi, self._upd, 1.0)
         self._upd_done.append((lo, hi))
+
+    def _transpose_table(self, lo, hi):
+        from ...ops import dense
+        key = (lo, hi)
+        if key not in self._tr_ranges:
+            a = self.arena
+            pairs = [(l.w_bf16, l.wt) for l in self.layers if l.trainable and lo <= a.offset_of(l.wi) < hi]
+            self._tr_ranges[key] = dense.make_transpose_table(pairs, self.device) if pairs else None
+        return self._tr_ranges[key]
+
+    def _apply_update(self, lo, hi, hyper, rescale):
+        """SGD-momentum on arena[lo:hi] + refresh of the bf16 / transposed working copies of that range."""
+        from ...ops import dense
+        lr, momentum, wd = hyper
+        a = self.arena
+        dense.sgd_momentum_update(a.w[lo:hi], a.g[lo:hi], a.m[lo:hi], a.wb[lo:hi], lr, momentum, wd, rescale)
+        table = self._transpose_table(lo, hi)
+        if table is not None:
+            dense.filter_transpose_batched(*table)
 
     # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
 
@@ -176,7 +208,17 @@ class DetectorBase:
         torch.cuda.synchronize()
         self._pool = torch.cuda.graph_pool_handle()
         self._pool_branch = torch.cuda.graph_pool_handle()
+        self._pool_opt = torch.cuda.graph_pool_handle()
         self.segments = []
+        self._buckets = []
+        self._cap_opt = None
+        self._final_join_opt = False
+        if self.dist is not None and self._seen_buckets:
+            # buckets seen in the eager warm-up: their transpose tables are built here, outside any capture
+            self.opt_stream = torch.cuda.Stream()
+            self._cap_opt = (lr, 0.9, 1e-4)
+            for lo_hi in sorted(self._seen_buckets):
+                self._transpose_table(*lo_hi)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -188,6 +230,8 @@ class DetectorBase:
             self._upd = None
             self.optimizer_step(lr)
             self._seg_end()
+            if self._final_join_opt:
+                self.segments.append(("join_opt",))
             self._cap = False
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -204,10 +248,21 @@ class DetectorBase:
                 self.static_masks.copy_(gt_masks, non_blocking=True)
         self.step_dev.fill_(step)
         fork_ev = None
+        handles = {}
         for seg in self.segments:
             if isinstance(seg, tuple):
                 if seg[0] == "reduce":
-                    self.reducer.reduce(seg[1], seg[2])
+                    h = self.reducer.reduce(seg[1], seg[2])
+                    if len(seg) > 3:
+                        handles[seg[3]] = h
+                elif seg[0] == "update":
+                    with torch.cuda.stream(self.opt_stream):
+                        for h in handles.get(seg[2], ()):
+                            h.wait()                       # orders the optimizer stream after the bucket's sums
+                        seg[1].replay()
+                elif seg[0] == "join_opt":
+                    torch.cuda.current_stream().wait_stream(self.opt_stream)
+                    self.reducer.pending, self.reducer.log = [], []
                 elif seg[0] == "fork":
                     fork_ev = torch.cuda.Event()
                     fork_ev.record()
@@ -241,6 +296,14 @@ class DetectorBase:
                 self._update_range(lo, hi)
             self._upd = None
             self.ws.join()
+            return
+        if self._cap and self.dist is not None and self._cap_opt is not None:
+            pos = 0
+            for lo, hi in sorted(self._buckets):
+                assert lo <= pos, "parameter range [%d, %d) belongs to no gradient bucket" % (pos, lo)
+                pos = max(pos, hi)
+            assert pos >= self.arena.size, "parameter range [%d, %d) belongs to no gradient bucket" % (pos, self.arena.size)
+            self._final_join_opt = True      # every bucket has its own update graph; capture() appends the join
             return
         if self._cap:
             if self.dist is not None:

@@ -15,15 +15,19 @@ class BucketReducer:
         self.log = []          # (lo, hi) of every all-reduce issued since the last wait()
 
     def reduce(self, lo, hi):
-        """All-reduce g[lo:hi] asynchronously, split into <= cap-element messages."""
+        """All-reduce g[lo:hi] asynchronously, split into <= cap-element messages. Returns this bucket's work handles
+        (waiting on them from a stream orders that stream after the bucket's sums; wait() does it for all buckets)."""
         if self.dist is None or hi <= lo:
-            return
+            return []
         s = lo
+        mine = []
         while s < hi:
             e = min(hi, s + self.cap)
-            self.pending.append(self.dist.all_reduce(self.g[s:e], async_op=True))
+            mine.append(self.dist.all_reduce(self.g[s:e], async_op=True))
             self.log.append((s, e))
             s = e
+        self.pending.extend(mine)
+        return mine
 
     def wait(self):
         for w in self.pending:
