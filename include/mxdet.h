@@ -68,6 +68,26 @@ int mxdet_nms_batched(const float* boxes, const int32_t* counts, const uint8_t* 
                       mxdet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * core/evaluation (README.md:20) + ops (README.md:24) -- test-time detection post-processing
+ * (MXNet-lineage role: the host-side im_detect -> per-class threshold -> nms ->
+ * max_per_image loop of py-faster-rcnn / mx-rcnn).
+ * cls_logits [N*R, ld_cls] (columns 0..C-1, class 0 = background) and bbox_pred [N*R, ld_reg] (class-specific
+ * deltas, 4 per class, normalised: delta = pred * stds + means) in `dtype`; rois [N*R,5] = (image, x1,y1,x2,y2), the
+ * first num_rois[n] rows of image n valid; im_info [N,3] = (h, w, scale).
+ * score = softmax(logits) (m = max, e_c = exp(x_c - m), s = sum in class order, e_c / s); box = decode + clip.
+ * Per image and foreground class: keep score > score_thresh, sort by (score desc, roi asc), greedy NMS at
+ * nms_thresh; then the max_per_image best over all classes by (score desc, roi asc, class asc).
+ * dets [N, max_per_image, 6] = (x1, y1, x2, y2, score, class), padding rows zero with class -1; num_dets [N]. */
+size_t mxdet_detection_postprocess_workspace_bytes(int32_t N, int32_t rois_per_image, int32_t num_classes);
+int mxdet_detection_postprocess(const void* cls_logits, const void* bbox_pred, int32_t dtype, int32_t ld_cls,
+                                int32_t ld_reg, const float* rois, const int32_t* num_rois, const float* im_info,
+                                int32_t N, int32_t rois_per_image, int32_t num_classes, const float* means,
+                                const float* stds, float score_thresh, float nms_thresh, int32_t max_per_image,
+                                float* dets, int32_t* num_dets, void* workspace, size_t workspace_bytes,
+                                mxdet_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------------
  * rpn_heads + ops (README.md:28, :24) -- pyramid proposal generation.
  * MXNet role: contrib.Proposal / MultiProposal, or the lineage's pyramid-proposal CustomOp.
  * Per image and level: top `pre_nms_top_n` anchors by objectness logit (ties: lower anchor index

@@ -53,6 +53,9 @@ SIGNATURES = {
     "mxdet_generate_anchors": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_nms_batched_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "mxdet_nms_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_detection_postprocess_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "mxdet_detection_postprocess": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                            P(c_f32), P(c_f32), c_f32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_proposal_workspace_bytes": (c_sz, [P(PyramidT), c_i32, c_i32]),
     "mxdet_proposal": (c_i32, [P(PyramidT), c_i32, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_sz, c_vp]),

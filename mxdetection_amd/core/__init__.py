@@ -1,2 +1,2 @@
 """core/{anchor,bbox,mask,loss} -- host-side mirror of /root/reference/README.md:15-19 over the HIP C-ABI."""
-from . import anchor, bbox, loss, mask  # noqa: F401
+from . import anchor, bbox, evaluation, loss, mask  # noqa: F401

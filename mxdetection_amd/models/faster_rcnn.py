@@ -120,6 +120,27 @@ class FasterRCNN(DetectorBase):
             return rpn_loss, rcnn_loss, mask_loss
         return rpn_loss, rcnn_loss
 
+    def predict(self, image, im_info, score_thresh=0.05, nms_thresh=0.5, max_per_image=100):
+        """Inference: forward, proposals, box head, then softmax / decode / per-class NMS / top-k on the GPU
+        (core/evaluation, SURVEY.md section 8f rank 3). Returns (dets [N,max_per_image,6] = x1,y1,x2,y2,score,class;
+        num_dets [N])."""
+        from ..core.evaluation import DetectionPostprocess
+        N, _, H, W = image.shape
+        g_max = self.planned[3] if self.planned is not None and self.planned[:3] == (N, H, W) else 100
+        self.plan(N, H, W, g_max)
+        P = self.neck.forward(self.backbone.forward(image))
+        self.rpn_head.forward(P)
+        rois, _, _, num_rois = self.rpn_head.get_proposals(im_info)
+        pooled = self.roi_extractor.forward(P, rois.view(-1, 5))
+        o = self.bbox_head.forward(pooled)
+        o2 = o.view(o.shape[0], -1)
+        key = (score_thresh, nms_thresh, max_per_image)
+        if getattr(self, "_post_key", None) != key:
+            self._post = DetectionPostprocess(self.bbox_head.nc, score_thresh, nms_thresh, max_per_image,
+                                              stds=self.bbox_head.stds)
+            self._post_key = key
+        return self._post(o2[:, :self.bbox_head.nc], o2[:, self.bbox_head.nc:], rois.view(-1, 5), num_rois, im_info)
+
     def _backbone_stage_backward(self, si):
         stage = self.backbone.stages[si]
         ds = self.dC[si]

@@ -790,3 +790,78 @@ API void oracle_decode_clip(const float* box, const float* d, float im_h, float 
   o_decode_clip(box, d, im_h, im_w, out);
 }
 API void oracle_encode(const float* ex, const float* gt, float* out) { o_encode(ex, gt, out); }
+
+/* ---- test-time detection post-processing (follows the contract in include/mxdet.h:
+ * "core/evaluation ... mxdet_detection_postprocess"; MXNet-lineage role: im_detect + per-class nms + max_per_image) --- */
+typedef struct { uint32_t key; uint32_t roi; uint32_t cls; float box[4]; float score; } o_det;
+static int o_cmp_det_cls(const void* a, const void* b) {      /* inside one class: score desc, roi asc */
+  const o_det* x = (const o_det*)a; const o_det* y = (const o_det*)b;
+  if (x->key != y->key) return x->key > y->key ? -1 : 1;
+  if (x->roi != y->roi) return x->roi < y->roi ? -1 : 1;
+  return 0;
+}
+static int o_cmp_det_all(const void* a, const void* b) {      /* whole image: score desc, roi asc, class asc */
+  const o_det* x = (const o_det*)a; const o_det* y = (const o_det*)b;
+  if (x->key != y->key) return x->key > y->key ? -1 : 1;
+  if (x->roi != y->roi) return x->roi < y->roi ? -1 : 1;
+  if (x->cls != y->cls) return x->cls < y->cls ? -1 : 1;
+  return 0;
+}
+/* cls [N*R][C] f32, reg [N*R][4C] f32, rois [N*R][5]; dets [N][max_det][6]; scores_out/boxes_out optional */
+API void oracle_detection_postprocess(const float* cls, const float* reg, const float* rois, const int32_t* num_rois,
+                                      const float* im_info, int N, int R, int C, const float* means,
+                                      const float* stds, float score_thresh, float nms_thresh, int max_det,
+                                      float* dets, int32_t* num_dets, float* scores_out, float* boxes_out) {
+  o_det* cand = (o_det*)malloc(sizeof(o_det) * (size_t)(R > 0 ? R : 1));
+  o_det* kept = (o_det*)malloc(sizeof(o_det) * (size_t)(R > 0 ? R : 1) * (size_t)C);
+  float* bx = (float*)malloc(sizeof(float) * 4 * (size_t)(R > 0 ? R : 1));
+  int32_t* keep = (int32_t*)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+  float* sc = (float*)malloc(sizeof(float) * (size_t)R * C);
+  float* bb = (float*)malloc(sizeof(float) * (size_t)R * C * 4);
+  for (int n = 0; n < N; ++n) {
+    int nr = num_rois[n]; nr = nr > R ? R : (nr < 0 ? 0 : nr);
+    for (int i = 0; i < R; ++i) {
+      const size_t r = (size_t)n * R + i;
+      for (int c = 0; c < C; ++c) { sc[(size_t)i * C + c] = 0.0f; for (int k = 0; k < 4; ++k) bb[((size_t)i * C + c) * 4 + k] = 0.0f; }
+      if (i >= nr) continue;
+      float m = cls[r * C];
+      for (int c = 1; c < C; ++c) m = cls[r * C + c] > m ? cls[r * C + c] : m;
+      float s = 0.0f;
+      for (int c = 0; c < C; ++c) s = s + mxdet_expf(cls[r * C + c] - m);
+      for (int c = 0; c < C; ++c) {
+        float e = mxdet_expf(cls[r * C + c] - m);
+        sc[(size_t)i * C + c] = e / s;
+        float d[4];
+        for (int k = 0; k < 4; ++k) d[k] = reg[r * 4 * C + 4 * c + k] * stds[k] + means[k];
+        o_decode_clip(rois + r * 5 + 1, d, im_info[n * 3], im_info[n * 3 + 1], bb + ((size_t)i * C + c) * 4);
+      }
+    }
+    if (scores_out) memcpy(scores_out + (size_t)n * R * C, sc, sizeof(float) * (size_t)R * C);
+    if (boxes_out) memcpy(boxes_out + (size_t)n * R * C * 4, bb, sizeof(float) * (size_t)R * C * 4);
+    int nkept = 0;
+    for (int c = 1; c < C; ++c) {
+      int nc = 0;
+      for (int i = 0; i < nr; ++i) {
+        float s = sc[(size_t)i * C + c];
+        if (s > score_thresh) {
+          cand[nc].key = o_float_key(s); cand[nc].roi = (uint32_t)i; cand[nc].cls = (uint32_t)c; cand[nc].score = s;
+          memcpy(cand[nc].box, bb + ((size_t)i * C + c) * 4, 16);
+          ++nc;
+        }
+      }
+      qsort(cand, (size_t)nc, sizeof(o_det), o_cmp_det_cls);
+      for (int j = 0; j < nc; ++j) memcpy(bx + 4 * j, cand[j].box, 16);
+      int nk = oracle_nms(bx, nc, NULL, nms_thresh, max_det, keep);
+      for (int j = 0; j < nk; ++j) kept[nkept++] = cand[keep[j]];
+    }
+    qsort(kept, (size_t)nkept, sizeof(o_det), o_cmp_det_all);
+    int nout = nkept < max_det ? nkept : max_det;
+    for (int j = 0; j < max_det; ++j) {
+      float* d = dets + ((size_t)n * max_det + j) * 6;
+      if (j < nout) { memcpy(d, kept[j].box, 16); d[4] = kept[j].score; d[5] = (float)kept[j].cls; }
+      else { d[0] = d[1] = d[2] = d[3] = d[4] = 0.0f; d[5] = -1.0f; }
+    }
+    num_dets[n] = nout;
+  }
+  free(cand); free(kept); free(bx); free(keep); free(sc); free(bb);
+}

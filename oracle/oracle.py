@@ -341,3 +341,20 @@ def maxpool3x3s2(x):
     y = np.zeros((N, Ho, Wo, Cc), np.float32)
     lib().oracle_maxpool3x3s2(_vp(x), C.c_int(N), C.c_int(H), C.c_int(W_), C.c_int(Cc), _vp(y))
     return y
+
+
+def detection_postprocess(cls, reg, rois, num_rois, im_info, means, stds, score_thresh, nms_thresh, max_det):
+    """cls [N*R, C] f32, reg [N*R, 4C] f32, rois [N*R, 5]. Returns dets [N,max_det,6], num [N], scores [N*R,C], boxes [N*R,C,4]."""
+    cls, reg, rois = _c(cls, np.float32), _c(reg, np.float32), _c(rois, np.float32)
+    N = int(np.asarray(im_info).shape[0])
+    Cn = cls.shape[1]
+    R = cls.shape[0] // N
+    dets = np.zeros((N, max_det, 6), np.float32)
+    num = np.zeros((N,), np.int32)
+    sc = np.zeros((N * R, Cn), np.float32)
+    bb = np.zeros((N * R, Cn, 4), np.float32)
+    lib().oracle_detection_postprocess(_vp(cls), _vp(reg), _vp(rois), _vp(_c(num_rois, np.int32)), _vp(_c(im_info, np.float32)),
+                                       C.c_int(N), C.c_int(R), C.c_int(Cn), _vp(_c(means, np.float32)), _vp(_c(stds, np.float32)),
+                                       C.c_float(score_thresh), C.c_float(nms_thresh), C.c_int(max_det), _vp(dets), _vp(num),
+                                       _vp(sc), _vp(bb))
+    return dets, num, sc, bb

@@ -84,3 +84,32 @@ def test_sampling_is_a_pure_function_of_the_key(oracle):
     assert k1 == oracle.sample_key(99, 3, 1, 0, 12345)
     assert k1 != oracle.sample_key(99, 3, 1, 1, 12345)
     assert k1 == int(oracle.philox((12345, 0, 1, 3), (99, 0x6D786474))[0])
+
+
+def test_detection_postprocess_known_answers(oracle):
+    """Hand-checkable cases of the test-time post-processing contract (include/mxdet.h, core/evaluation)."""
+    C = 3
+    # three rois of one image; zero deltas -> boxes are the rois, clipped to the 100x100 image
+    rois = np.array([[0, 10, 10, 49, 49], [0, 12, 12, 51, 51], [0, 60, 60, 120, 90]], np.float32)
+    reg = np.zeros((3, 4 * C), np.float32)
+    # logits chosen so that softmax is exact in binary: (0, ln-free) -> use equal logits per row
+    cls = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]], np.float32)     # every score = 1/3
+    info = np.array([[100.0, 100.0, 1.0]], np.float32)
+    dets, num, sc, bb = oracle.detection_postprocess(cls, reg, rois, [3], info, (0, 0, 0, 0), (1, 1, 1, 1), 0.1, 0.5, 10)
+    assert np.allclose(sc, 1.0 / 3.0) and np.array_equal(bb[2, 1], [60, 60, 99, 90])    # third roi clipped at x = 99
+    # rois 0 and 1 overlap with IoU = 38*38 / (2*1600 - 1444) = 0.822 > 0.5: the lower index survives, per class
+    assert int(num[0]) == 4
+    got = dets[0, :4]
+    # all scores tie: order is (roi asc, class asc)
+    assert np.array_equal(got[:, 5], [1, 2, 1, 2])
+    assert np.array_equal(got[0, :4], [10, 10, 49, 49]) and np.array_equal(got[2, :4], [60, 60, 99, 90])
+    assert np.all(dets[0, 4:, 5] == -1)
+    # only the first num_rois rows count
+    dets, num, _, _ = oracle.detection_postprocess(cls, reg, rois, [1], info, (0, 0, 0, 0), (1, 1, 1, 1), 0.1, 0.5, 10)
+    assert int(num[0]) == 2
+    # a confident class: logits (0, ln 3, 0)... use the expf restatement's own value for the expectation
+    cls2 = np.array([[0.0, 2.0, 0.0]] * 3, np.float32)
+    dets, num, sc, _ = oracle.detection_postprocess(cls2, reg, rois, [3], info, (0, 0, 0, 0), (1, 1, 1, 1), 0.5, 0.5, 10)
+    e = np.float32(oracle.expf(np.float32(-2.0)))
+    want = np.float32(1.0) / (e + np.float32(1.0) + e)
+    assert sc[0, 1] == want and int(num[0]) == 2 and np.all(dets[0, :2, 5] == 1)
