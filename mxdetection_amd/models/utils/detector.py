@@ -51,6 +51,67 @@ class DetectorBase:
                 out[l.name + ".bias"] = l.bias_f32.float().cpu()
         return out
 
+    # ---- checkpoints: MXNet NDArray-list container, MXNet tensor layouts ----
+
+    def _named_tensors(self):
+        """(name, kind, tensor) of every stored parameter: trainable master weights (fp32 arena views), frozen filters
+        (bf16) and folded frozen-BN shifts (fp32)."""
+        out = [("stem.weight", "frozen", self.backbone.stem_w), ("stem.bias", "frozen", self.backbone.stem_b)]
+        frozen = [l for st in self.backbone.stages for b in st for l in b.layers() if not l.trainable]
+        seen = set()
+        for l in list(self.layers) + frozen:
+            if id(l) in seen:
+                continue
+            seen.add(id(l))
+            if l.trainable:
+                out.append((l.name + ".weight", "w", self.arena.view(l.wi, "w")))
+                if l.train_bias:
+                    out.append((l.name + ".bias", "w", self.arena.view(l.bi, "w")))
+                elif l.has_bias:
+                    out.append((l.name + ".bias", "frozen", l.frozen_bias))
+            else:
+                out.append((l.name + ".weight", "frozen", l.w_bf16))
+                if l.has_bias:
+                    out.append((l.name + ".bias", "frozen", l.bias_f32))
+        return out
+
+    def save_checkpoint(self, path):
+        """Write every parameter ("arg:<name>", filters in MXNet's OIHW layout, fp32) and the SGD momentum of the
+        trainable ones ("aux:momentum:<name>") as an MXNet 1.3.0 `.params` file (utils/params_io.py)."""
+        from ...utils import save_params
+        to_mx = lambda t: (t.permute(0, 3, 1, 2) if t.dim() == 4 else t).float().contiguous().cpu().numpy()  # noqa: E731
+        blob = {}
+        for name, kind, t in self._named_tensors():
+            blob["arg:" + name] = to_mx(t)
+        for i, e in enumerate(self.arena.entries):
+            blob["aux:momentum:" + e[0]] = to_mx(self.arena.view(i, "m"))
+        save_params(path, blob)
+
+    def load_checkpoint(self, path, strict=True):
+        """Inverse of save_checkpoint; refreshes the bf16 / transposed working copies. Returns the names not found."""
+        from ...utils import load_params
+        blob = load_params(path)
+        from_mx = lambda a, like: torch.from_numpy(a).to(like.device).permute(0, 2, 3, 1) if a.ndim == 4 else torch.from_numpy(a).to(like.device)  # noqa: E731,E501
+        missing = []
+        for name, kind, t in self._named_tensors():
+            a = blob.get("arg:" + name)
+            if a is None:
+                missing.append(name)
+                continue
+            src = from_mx(a, t)
+            assert tuple(src.shape) == tuple(t.shape), "%s: checkpoint %s vs model %s" % (name, tuple(src.shape), tuple(t.shape))
+            t.copy_(src.to(t.dtype))
+        for i, e in enumerate(self.arena.entries):
+            a = blob.get("aux:momentum:" + e[0])
+            if a is not None:
+                m = self.arena.view(i, "m")
+                m.copy_(from_mx(a, m))
+        if strict and missing:
+            raise KeyError("checkpoint lacks %d parameters, e.g. %s" % (len(missing), missing[:3]))
+        self.arena.refresh_bf16()
+        self.refresh_transposed()
+        return missing
+
     def export_grads(self):
         """name -> fp32 CPU gradient of every trainable parameter."""
         return {e[0]: self.arena.view(i, "g").float().cpu() for i, e in enumerate(self.arena.entries)}

@@ -129,3 +129,28 @@ def test_gradient_exchange_path_matches_single_gpu_step(hip):
     assert torch.allclose(l_single[2:], l_par[2:], rtol=5e-2, atol=1e-2), (l_single, l_par)
     assert (w_single - w_par).abs().max().item() <= 1e-2 * moved
     assert (wb_single - wb_par).abs().max().item() <= 2e-2 * wb_single.abs().max().item()
+
+
+def test_checkpoint_round_trip(hip, tmp_path):
+    """save_checkpoint / load_checkpoint (MXNet .params container): a differently initialised model that loads the
+    file computes the same step, bit for bit in everything that does not go through fp32 atomics."""
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    from mxdetection_amd.utils import load_params
+    N, H, W = 1, 192, 256
+    image, gt, im_info = _inputs(N, H, W, seed=4)
+    a = FasterRCNN("cuda", seed=7, pre_nms_top_n=600, post_nms_top_n=300, rois_per_image=128)
+    a.train_step(image, gt, im_info, step=0, lr=0.001)          # non-trivial momentum
+    fn = str(tmp_path / "frcnn-0001.params")
+    a.save_checkpoint(fn)
+    blob = load_params(fn)
+    assert blob["arg:rpn.conv.weight"].shape == (256, 256, 3, 3)            # MXNet OIHW layout on disk
+    assert "aux:momentum:bbox.fc1.weight" in blob
+    b = FasterRCNN("cuda", seed=11, pre_nms_top_n=600, post_nms_top_n=300, rois_per_image=128)
+    assert not torch.equal(a.arena.w, b.arena.w)
+    assert b.load_checkpoint(fn) == []
+    assert torch.equal(a.arena.w, b.arena.w) and torch.equal(a.arena.m, b.arena.m) and torch.equal(a.arena.wb, b.arena.wb)
+    la = torch.cat(a.forward_backward(image, gt, im_info, step=1)).clone()
+    lb = torch.cat(b.forward_backward(image, gt, im_info, step=1)).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb)
