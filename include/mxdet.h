@@ -300,6 +300,27 @@ int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy, const uin
 size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d);
 int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* dy, float* dw,
                        float* db, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+/* Grouped weight gradients: the wgrads of many layers (a ResNet stage, the FPN, a head) in ONE launch pair (MFMA
+ * workgroups of all layers in one grid + one fold launch). At batch 2 a layer's own grid is one or two workgroups per
+ * CU; a group runs at the occupancy of the largest layers, needs less split-K and two launches instead of 2 per layer.
+ * Usage: fill items[] (descriptor + device pointers, accumulate honoured per item), call _plan once per group -- it
+ * writes a table of mxdet_conv2d_wgrad_grouped_table_bytes(n) bytes to HOST memory and reports the workspace size and
+ * the two grid sizes --, copy the table to device memory (it stays valid while the pointers do, e.g. across hipGraph
+ * replays), then launch with mxdet_conv2d_wgrad_grouped. Results equal mxdet_conv2d_wgrad's up to the split-K
+ * partition (fp32 sums in a different, still fixed, order). */
+typedef struct {
+  mxdet_conv_desc_t desc;
+  const void* x;    /* bf16 [N,H,W,Cin] */
+  const void* dy;   /* bf16 [N,Ho,Wo,Cout] */
+  float* dw;        /* f32 [Cout,KH,KW,Cin] */
+  float* db;        /* f32 [Cout] or NULL */
+} mxdet_wgrad_item_t;
+size_t mxdet_conv2d_wgrad_grouped_table_bytes(int32_t n);
+int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, void* table_host, size_t table_bytes,
+                                    size_t* workspace_bytes, int32_t* grid_wgrad, int32_t* grid_reduce);
+int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_reduce,
+                               void* workspace, size_t workspace_bytes, size_t workspace_needed,
+                               mxdet_stream_t stream);
 /* tuning / test hook: force the conv tile configuration on this thread (0 = built-in heuristic,
  * 1..8 = a specific tile/ring configuration, see conv.hip launch()) */
 int mxdet_debug_force_conv_cfg(int32_t cfg);

@@ -32,6 +32,10 @@ class FeatPyramidT(C.Structure):
     ]
 
 
+class WgradItemT(C.Structure):
+    pass
+
+
 class ConvDescT(C.Structure):
     _fields_ = [
         ("N", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32),
@@ -41,6 +45,8 @@ class ConvDescT(C.Structure):
         ("relu", c_i32), ("res_upsample", c_i32), ("accumulate", c_i32),
     ]
 
+
+WgradItemT._fields_ = [("desc", ConvDescT), ("x", c_vp), ("dy", c_vp), ("dw", c_vp), ("db", c_vp)]
 
 P = C.POINTER
 
@@ -93,6 +99,9 @@ SIGNATURES = {
     "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_conv2d_wgrad_workspace_bytes": (c_sz, [P(ConvDescT)]),
     "mxdet_conv2d_wgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_conv2d_wgrad_grouped_table_bytes": (c_sz, [c_i32]),
+    "mxdet_conv2d_wgrad_grouped_plan": (c_i32, [P(WgradItemT), c_i32, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32)]),
+    "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_debug_force_wgrad_ksplit": (c_i32, [c_i32]),
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -65,8 +65,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // of step t+1 are in flight while step t is multiplied; one s_waitcnt vmcnt(0) + one raw s_barrier per step.
 // The LDS image is lane-linear, so the granule swizzle is applied to the per-lane SOURCE chunk.
 template <int BKP, int NS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-wgrad_kernel(WgradP p) {
+__device__ __forceinline__ void wgrad_tile(const WgradP& p, int b) {
   constexpr int GI = BKP / 16;      // DMA instructions per wave per image per stage (4 pixel rows each)
   static_assert(NS >= 2 && (NS - 2) * 2 * (BKP / 16) <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS][2][BKP * 256];  // [buf][dy|x]
@@ -75,7 +74,6 @@ wgrad_kernel(WgradP p) {
   const int wm = wid >> 1, wn = wid & 1;
   // XCD-aware order with the tap fastest: the KH*KW workgroups that share one (dy tile, shifted x tile)
   // pair sit next to each other in one XCD's queue and hit that XCD's L2 for 8 of 9 reads.
-  int b = blockIdx.x;
   if (b >= p.nwg_main) {
     // bias-gradient workgroups (appended to the grid, they stream dy while the MFMA workgroups compute):
     // column sums of this split's pixel range for one 128-channel co tile, fixed order
@@ -296,6 +294,43 @@ wgrad_kernel(WgradP p) {
     }
 }
 
+template <int BKP, int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+wgrad_kernel(WgradP p) {
+  wgrad_tile<BKP, NS>(p, (int)blockIdx.x);
+}
+
+// ---- grouped form: the weight gradients of MANY layers in one launch ----------------------------------------------
+// A ResNet stage at batch 2 is 10-20 layers whose own grids (one or two workgroups per CU, 17-step K loops, a slab
+// fold each) leave the chip latency-bound; issued as one grid of a few thousand workgroups they run at the
+// occupancy the big P2-level layers get, need 3-4x less split-K (slab traffic) and two launches instead of 40.
+// The table lives in device memory (built once per group by mxdet_conv2d_wgrad_grouped_plan, pointers are static
+// under hipGraph replay); slab addresses are offsets from the workspace passed at launch.
+struct WgradG {
+  WgradP p;                 // slab / bslab hold byte offsets into the workspace
+  int block0, nblocks;      // this layer's workgroups: [block0, block0 + nblocks), block0 a multiple of 8
+  int rblock0, wblocks, bblocks;   // fold kernel: first workgroup, workgroups over dw, workgroups over db
+  int pad_;
+  long long nparams;
+};
+
+template <int BKP, int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
+  int lo = 0, hi = n - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int b = bid - table[lo].block0;
+  if (b >= table[lo].nblocks) return;            // alignment padding between layers
+  WgradP p = table[lo].p;
+  p.slab = (float*)(workspace + (size_t)p.slab);
+  p.bslab = (float*)(workspace + (size_t)p.bslab);
+  wgrad_tile<BKP, NS>(p, b);
+}
+
 // dw[i] (+)= sum_ks slab[ks][i] in index order; the trailing workgroups fold the bias partials the same way.
 // Four independent 16-B loads in flight per thread (the slabs are read exactly once: latency, not bandwidth, bounds
 // a small grid).
@@ -327,6 +362,58 @@ wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bs
   }
   for (; k < ksplit; ++k) {
     float4 v = *(const float4*)(sp + (long long)k * n);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (accumulate) {
+    float4 o = *(const float4*)(dw + i);
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  *(float4*)(dw + i) = s;
+}
+
+// fold kernel of the grouped form: one launch for every layer of the group
+__global__ void __launch_bounds__(256)
+wgrad_reduce_grouped_kernel(const WgradG* __restrict__ table, int n, const unsigned char* __restrict__ workspace) {
+  int lo = 0, hi = n - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid].rblock0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const WgradG& g = table[lo];
+  const int b = bid - g.rblock0;
+  const int ksplit = g.p.ksplit, Cout = g.p.Cout, accumulate = g.p.accumulate;
+  if (ksplit <= 1 || b >= g.wblocks + g.bblocks) return;      // single-split layers wrote dw / db directly
+  const float* slab = (const float*)(workspace + (size_t)g.p.slab);
+  const float* bslab = (const float*)(workspace + (size_t)g.p.bslab);
+  float* dw = g.p.dw;
+  float* db = g.p.db;
+  const long long nn = g.nparams;
+  if (b >= g.wblocks) {
+    int c = (b - g.wblocks) * 256 + threadIdx.x;
+    if (c >= Cout) return;
+    float s = bslab[c];
+    for (int k = 1; k < ksplit; ++k) s += bslab[(size_t)k * Cout + c];
+    db[c] = accumulate ? db[c] + s : s;
+    return;
+  }
+  long long i = ((long long)b * blockDim.x + threadIdx.x) * 4;
+  if (i >= nn) return;
+  const float* sp = slab + i;
+  float4 s = *(const float4*)sp;
+  int k = 1;
+  for (; k + 3 < ksplit; k += 4) {
+    float4 v0 = *(const float4*)(sp + (long long)k * nn);
+    float4 v1 = *(const float4*)(sp + (long long)(k + 1) * nn);
+    float4 v2 = *(const float4*)(sp + (long long)(k + 2) * nn);
+    float4 v3 = *(const float4*)(sp + (long long)(k + 3) * nn);
+    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+  }
+  for (; k < ksplit; ++k) {
+    float4 v = *(const float4*)(sp + (long long)k * nn);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   if (accumulate) {
@@ -484,6 +571,105 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
                        d->accumulate, dw, db);
   }
   return check_launch("conv2d_wgrad");
+}
+
+// ---- grouped weight gradients -----------------------------------------------------------------------------------------
+static int validate_wgrad_desc(const mxdet_conv_desc_t* d, const char* who) {
+  MXDET_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 &&
+                    d->stride > 0 && d->pad >= 0,
+                MXDET_ESHAPE, "%s: non-positive dimension", who);
+  MXDET_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 &&
+                    d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                MXDET_ESHAPE, "%s: Ho/Wo do not match the convolution arithmetic", who);
+  MXDET_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, MXDET_ESHAPE, "%s: Cin and Cout must be multiples of 8", who);
+  MXDET_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1ll << 31) &&
+                    (long long)d->N * d->Ho * d->Wo * d->Cout < (1ll << 31),
+                MXDET_ESHAPE, "%s: tensor exceeds 2^31 elements", who);
+  return MXDET_OK;
+}
+
+extern "C" size_t mxdet_conv2d_wgrad_grouped_table_bytes(int32_t n) {
+  return n > 0 ? (size_t)n * sizeof(WgradG) : 0;
+}
+
+extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, void* table_host,
+                                               size_t table_bytes, size_t* workspace_bytes, int32_t* grid_wgrad,
+                                               int32_t* grid_reduce) {
+  clear_error();
+  MXDET_REQUIRE(items && n > 0 && table_host && workspace_bytes && grid_wgrad && grid_reduce, MXDET_EINVAL,
+                "wgrad_grouped_plan: null pointer or empty group");
+  MXDET_REQUIRE(table_bytes >= (size_t)n * sizeof(WgradG), MXDET_EWORKSPACE, "wgrad_grouped_plan: table too small");
+  WgradG* t = (WgradG*)table_host;
+  size_t off = 0;
+  long long blocks = 0, rblocks = 0;
+  // pixels per workgroup: long enough K loops to amortise the 64-KiB slab a workgroup writes, short enough that the
+  // group has a few thousand workgroups; never below 16 steps
+  long long tiles_total = 0;
+  for (int i = 0; i < n; ++i)
+    tiles_total += (long long)ceil_div(items[i].desc.Cout, 128) * ceil_div(items[i].desc.Cin, 128) *
+                   items[i].desc.KH * items[i].desc.KW;
+  for (int i = 0; i < n; ++i) {
+    const mxdet_conv_desc_t* d = &items[i].desc;
+    int rc = validate_wgrad_desc(d, "wgrad_grouped_plan");
+    if (rc) return rc;
+    MXDET_REQUIRE(items[i].x && items[i].dy && items[i].dw, MXDET_EINVAL, "wgrad_grouped_plan: item %d: null pointer", i);
+    WgradG& g = t[i];
+    memset(&g, 0, sizeof(g));
+    WgradP& p = g.p;
+    p.x = (const uint16_t*)items[i].x; p.dy = (const uint16_t*)items[i].dy;
+    p.dw = items[i].dw; p.db = items[i].db; p.accumulate = d->accumulate;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = d->N * d->Ho * d->Wo;
+    p.co_tiles = ceil_div(d->Cout, 128); p.ci_tiles = ceil_div(d->Cin, 128);
+    const int taps = d->KH * d->KW;
+    const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
+    const int steps = ceil_div(p.M, kWgradBKP);
+    // aim for ~3000 workgroups over the group (3 rounds of the 1024 resident ones), 16..128 steps each
+    long long want = tiles_total > 0 ? (3072 + tiles_total - 1) / tiles_total : 1;
+    int ks = (int)want;
+    const int max_ks = steps / 16 > 0 ? steps / 16 : 1, min_ks = ceil_div(steps, 128);
+    ks = ks > max_ks ? max_ks : ks;
+    ks = ks < min_ks ? min_ks : ks;
+    ks = ks < 1 ? 1 : (ks > 64 ? 64 : ks);
+    p.steps_per_split = ceil_div(steps, ks);
+    p.ksplit = ceil_div(steps, p.steps_per_split);
+    const size_t params = (size_t)d->Cout * taps * d->Cin;
+    g.nparams = (long long)params;
+    p.slab = (float*)off;                                    // byte offsets; resolved against the workspace at launch
+    off += align_up((size_t)p.ksplit * params * sizeof(float), 256);
+    p.bslab = (float*)off;
+    off += align_up((size_t)p.ksplit * d->Cout * sizeof(float), 256);
+    p.nwg_main = (int)(tiles * p.ksplit);
+    g.nblocks = p.nwg_main + (p.db ? p.co_tiles * p.ksplit : 0);
+    g.block0 = (int)blocks;
+    blocks += align_up((size_t)g.nblocks, 8);
+    g.wblocks = p.ksplit > 1 ? (int)ceil_div<long long>((long long)params / 4, 256) : 0;
+    g.bblocks = (p.ksplit > 1 && p.db) ? ceil_div(d->Cout, 256) : 0;
+    g.rblock0 = (int)rblocks;
+    rblocks += g.wblocks + g.bblocks;
+    MXDET_REQUIRE(blocks < (1ll << 30) && rblocks < (1ll << 30), MXDET_ESHAPE, "wgrad_grouped_plan: group too large");
+  }
+  *workspace_bytes = off;
+  *grid_wgrad = (int32_t)blocks;
+  *grid_reduce = (int32_t)rblocks;
+  return MXDET_OK;
+}
+
+extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_reduce,
+                                          void* workspace, size_t workspace_bytes, size_t workspace_needed,
+                                          mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(table_dev && n > 0 && grid_wgrad > 0, MXDET_EINVAL, "wgrad_grouped: empty group");
+  MXDET_REQUIRE(workspace_needed == 0 || (workspace && workspace_bytes >= workspace_needed), MXDET_EWORKSPACE,
+                "wgrad_grouped: workspace %zu < %zu", workspace_bytes, workspace_needed);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid_wgrad), dim3(256), 0, s,
+                     (const WgradG*)table_dev, n, (unsigned char*)workspace);
+  if (grid_reduce > 0)
+    hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)grid_reduce), dim3(256), 0, s,
+                       (const WgradG*)table_dev, n, (const unsigned char*)workspace);
+  return check_launch("conv2d_wgrad_grouped");
 }
 
 extern "C" int mxdet_filter_transpose_batched(const void* descs_dev, int32_t ndesc, int32_t total_tiles,

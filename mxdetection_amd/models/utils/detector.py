@@ -187,7 +187,12 @@ class DetectorBase:
         self.world = world_size
         self.reducer = BucketReducer(self.arena.g, dist)
 
+    def enable_grouped_wgrad(self):
+        """Issue the weight gradients of each bucket (box/mask heads, FPN, every ResNet stage) as one grouped launch."""
+        self.ws.grouping = True
+
     def _reduce(self, lo, hi):
+        self.ws.flush()           # grouped mode: the bucket's recorded weight gradients go out now
         self.ws.join()            # the bucket's weight gradients were produced on the side stream
         if self._cap:
             if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
@@ -340,6 +345,7 @@ class DetectorBase:
         return self.static_losses
 
     def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
+        self.ws.flush()
         self.ws.join()
         done, self._upd_done = self._upd_done, []
         if done:

@@ -10,6 +10,7 @@ Design (MI355X-first, not MXNet's per-NDArray executor):
   * frozen BatchNorm (use_global_stats) is folded into the filters and a per-channel bias once at
     construction; frozen layers (stem, C2) keep bf16 filters only.
 """
+import contextlib
 import math
 
 import torch
@@ -29,6 +30,40 @@ class Workspace:
         self.need = 0
         self.buf = None
         self.side = None
+        # grouped mode: backward_weight() calls are recorded and issued together at flush() (one launch pair per
+        # group -- a ResNet stage, the FPN, a head -- instead of two launches per layer)
+        self.grouping = False
+        self.pending = []
+        self.plans = {}
+        self.gbuf = None
+
+    def defer(self, layer, x, dy):
+        self.pending.append((layer, x, dy))
+
+    def flush(self):
+        """Issue the recorded weight gradients (on the side stream if there is one)."""
+        if not self.pending:
+            return
+        items, self.pending = self.pending, []
+        key = tuple((id(l), x.data_ptr(), dy.data_ptr()) for l, x, dy in items)
+        plan = self.plans.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if plan is None and not capturing:
+            calls = [(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
+                      l.arena.view(l.bi, "g") if l.train_bias else None, False) for l, x, dy in items]
+            plan = dense.GroupedWgrad(calls, self.device)
+            self.plans[key] = plan
+            if self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
+                self.gbuf = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device=self.device)
+        ctx = self.fork()
+        with (ctx if ctx is not None else contextlib.nullcontext()):
+            if plan is None or self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
+                # first seen under capture (no eager warm-up): a table cannot be uploaded now -- per-layer launches
+                for l, x, dy in items:
+                    dense.conv2d_wgrad(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
+                                       l.arena.view(l.bi, "g") if l.train_bias else None, False, self.get())
+            else:
+                plan.launch(self.gbuf)
 
     def fork(self):
         if self.side is None:
@@ -148,6 +183,9 @@ class ConvLayer:
                                   accumulate, out)
 
     def backward_weight(self, x, dy, accumulate=False):
+        if self.ws.grouping and not accumulate:
+            self.ws.defer(self, x, dy)
+            return
         dw = self.arena.view(self.wi, "g")
         db = self.arena.view(self.bi, "g") if self.train_bias else None
         ctx = self.ws.fork()

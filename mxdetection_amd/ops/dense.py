@@ -66,6 +66,40 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=Fa
     return dw
 
 
+class GroupedWgrad:
+    """Weight gradients of several layers as one launch pair (mxdet_conv2d_wgrad_grouped). `calls` is a list of
+    (x, dy, KH, KW, stride, pad, dw, db, accumulate); the plan (device table, grids, workspace size) is built once, in
+    eager mode, and stays valid while the tensors keep their addresses (e.g. under hipGraph replay)."""
+
+    def __init__(self, calls, device):
+        lib = _lib.load()
+        n = len(calls)
+        items = (_lib.WgradItemT * n)()
+        self.keep = calls                     # the tensors whose addresses the table holds
+        self.flops = 0.0
+        self.heaviest = (0.0, "")
+        for it, (x, dy, KH, KW, stride, pad, dw, db, accumulate) in zip(items, calls):
+            N, H, W, Cin = x.shape
+            it.desc = conv_desc(N, H, W, Cin, dy.shape[3], KH, KW, stride, pad, accumulate=accumulate)
+            it.x, it.dy, it.dw, it.db = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+            fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * KH * KW * Cin
+            self.flops += fl
+            if fl > self.heaviest[0]:
+                self.heaviest = (fl, "N=%d %dx%d %d->%d %dx%d" % (N, H, W, Cin, dy.shape[3], KH, KW))
+        nbytes = lib.mxdet_conv2d_wgrad_grouped_table_bytes(n)
+        host = (C.c_ubyte * nbytes)()
+        ws, gw, gr = C.c_size_t(0), C.c_int32(0), C.c_int32(0)
+        check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gr)),
+              "conv2d_wgrad_grouped_plan")
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
+        self.n, self.grid_wgrad, self.grid_reduce, self.workspace_bytes = n, gw.value, gr.value, ws.value
+
+    def launch(self, workspace):
+        check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_reduce,
+                                                     ptr(workspace), workspace.numel() if workspace is not None else 0,
+                                                     self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
+
+
 def filter_transpose(w, out=None):
     lib = _lib.load()
     Cout, KH, KW, Cin = w.shape

@@ -61,7 +61,7 @@ def test_loss_decreases_on_a_fixed_batch(hip):
 
 
 def test_wgrad_side_stream_and_graph_replay_match_eager(hip):
-    """The overlapped schedule (weight gradients and the RPN training branch on forked streams, whole step replayed from hipGraphs) computes the
+    """The overlapped schedule (grouped weight gradients and the RPN training branch on forked streams, whole step replayed from hipGraphs) computes the
     same step as plain eager launches: identical losses, gradients equal up to fp32-atomic ordering in RoIAlign-bwd."""
     import torch
     from mxdetection_amd.models import FasterRCNN
@@ -73,6 +73,7 @@ def test_wgrad_side_stream_and_graph_replay_match_eager(hip):
     m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
     m.enable_wgrad_stream()
     m.enable_branch_stream()
+    m.enable_grouped_wgrad()
     l_side = torch.cat(m.forward_backward(image, gt, im_info, step=4, image_offset=0)).clone()
     m.ws.join()
     torch.cuda.synchronize()
