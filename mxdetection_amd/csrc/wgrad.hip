@@ -625,10 +625,13 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
     const int taps = d->KH * d->KW;
     const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
     const int steps = ceil_div(p.M, kWgradBKP);
-    // aim for ~3000 workgroups over the group (3 rounds of the 1024 resident ones), 16..128 steps each
-    long long want = tiles_total > 0 ? (3072 + tiles_total - 1) / tiles_total : 1;
+    // aim for ~3000 workgroups over the group (3 rounds of the 1024 resident ones)
+    // measured sweep (profiles/r01_h_grouped_wgrad_sweep.txt): ~3072 workgroups per group, 64..128 steps each
+    const long long target = 3072;
+    const int min_steps = 64;
+    long long want = tiles_total > 0 ? (target + tiles_total - 1) / tiles_total : 1;
     int ks = (int)want;
-    const int max_ks = steps / 16 > 0 ? steps / 16 : 1, min_ks = ceil_div(steps, 128);
+    const int max_ks = steps / min_steps > 0 ? steps / min_steps : 1, min_ks = ceil_div(steps, 128);
     ks = ks > max_ks ? max_ks : ks;
     ks = ks < min_ks ? min_ks : ks;
     ks = ks < 1 ? 1 : (ks > 64 ? 64 : ks);
