@@ -101,6 +101,15 @@ class ConvTimer:
                 timer.log.append(("conv_wgrad", plan.flops, orig_launch, (plan, workspace), {}))
             return orig_launch(plan, workspace)
         dense.GroupedWgrad.launch = grouped_launch
+        orig_glaunch = dense.GroupedConv.launch
+        timer.orig["GroupedConv.launch"] = orig_glaunch
+
+        def grouped_conv_launch(plan):
+            if timer.logging:
+                timer.log.append(("conv_igemm_fwd" if plan.kind == 0 else "conv_igemm_dgrad", plan.flops, orig_glaunch,
+                                  (plan,), {}))
+            return orig_glaunch(plan)
+        dense.GroupedConv.launch = grouped_conv_launch
 
     @staticmethod
     def time_launch(fn, a, kw, reps):
@@ -129,7 +138,7 @@ class ConvTimer:
             acc[0] += flops
             acc[1] += t
             acc[2] += 1
-            grouped = fn is self.orig.get("GroupedWgrad.launch")     # "heaviest" = the largest SINGLE-layer launch
+            grouped = fn in (self.orig.get("GroupedWgrad.launch"), self.orig.get("GroupedConv.launch"))   # "heaviest" = the largest SINGLE-layer launch
             if not grouped and (family not in self.heaviest or flops > self.heaviest[family][0]):
                 self.heaviest[family] = (flops, t)
         return fam

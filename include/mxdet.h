@@ -300,6 +300,27 @@ int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy, const uin
 size_t mxdet_conv2d_wgrad_workspace_bytes(const mxdet_conv_desc_t* d);
 int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* dy, float* dw,
                        float* db, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+/* Grouped convolutions: independent forward convolutions (kind 0) or stride-1 data gradients (kind 1) that can share
+ * one tile configuration -- the 3x3 of every pyramid level of an RPN / RetinaNet head, the FPN output convs -- as ONE
+ * grid: the small levels ride in the shadow of the large ones instead of running latency-bound on their own.
+ * Same protocol as the grouped weight gradients: _plan writes a host table (+ tile configuration and grid size), the
+ * caller uploads it once, mxdet_conv2d_grouped launches it. Per item the semantics are exactly those of
+ * mxdet_conv2d_fwd (src = x, filt = w, dst = y; bias / residual / desc.relu / desc.res_upsample) or
+ * mxdet_conv2d_dgrad (src = dy, filt = wt, dst = dx; residual / relu_mask / desc.accumulate). */
+typedef struct {
+  mxdet_conv_desc_t desc;
+  const void* src;
+  const void* filt;
+  const float* bias;
+  const void* residual;
+  const void* relu_mask;
+  void* dst;
+} mxdet_conv_item_t;
+size_t mxdet_conv2d_grouped_table_bytes(int32_t n);
+int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t n, int32_t kind, void* table_host,
+                              size_t table_bytes, int32_t* cfg, int32_t* grid);
+int mxdet_conv2d_grouped(const void* table_dev, int32_t n, int32_t kind, int32_t cfg, int32_t grid,
+                         mxdet_stream_t stream);
 /* Grouped weight gradients: the wgrads of many layers (a ResNet stage, the FPN, a head) in ONE launch pair (MFMA
  * workgroups of all layers in one grid + one fold launch). At batch 2 a layer's own grid is one or two workgroups per
  * CU; a group runs at the occupancy of the largest layers, needs less split-K and two launches instead of 2 per layer.

@@ -36,6 +36,10 @@ class WgradItemT(C.Structure):
     pass
 
 
+class ConvItemT(C.Structure):
+    pass
+
+
 class ConvDescT(C.Structure):
     _fields_ = [
         ("N", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32),
@@ -47,6 +51,8 @@ class ConvDescT(C.Structure):
 
 
 WgradItemT._fields_ = [("desc", ConvDescT), ("x", c_vp), ("dy", c_vp), ("dw", c_vp), ("db", c_vp)]
+ConvItemT._fields_ = [("desc", ConvDescT), ("src", c_vp), ("filt", c_vp), ("bias", c_vp), ("residual", c_vp),
+                      ("relu_mask", c_vp), ("dst", c_vp)]
 
 P = C.POINTER
 
@@ -99,6 +105,9 @@ SIGNATURES = {
     "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_conv2d_wgrad_workspace_bytes": (c_sz, [P(ConvDescT)]),
     "mxdet_conv2d_wgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_conv2d_grouped_table_bytes": (c_sz, [c_i32]),
+    "mxdet_conv2d_grouped_plan": (c_i32, [P(ConvItemT), c_i32, c_i32, c_vp, c_sz, P(c_i32), P(c_i32)]),
+    "mxdet_conv2d_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mxdet_conv2d_wgrad_grouped_table_bytes": (c_sz, [c_i32]),
     "mxdet_conv2d_wgrad_grouped_plan": (c_i32, [P(WgradItemT), c_i32, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32)]),
     "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),

@@ -61,8 +61,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // One counted s_waitcnt vmcnt + one raw s_barrier per K-step; the LDS image is lane-linear, so the
 // conflict-avoiding XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read side.
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
-__global__ void __launch_bounds__(64 * WM * WN)
-conv_igemm_kernel(ConvP p) {
+__device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -84,8 +83,6 @@ conv_igemm_kernel(ConvP p) {
 
   // XCD-aware tile order: blocks that share an XCD (bid % 8) walk consecutive tiles, and consecutive
   // tiles share their A rows (n fastest), so the A tile is re-read from that XCD's L2.
-  int bid = blockIdx.x;
-  const int nwg = gridDim.x;
   if constexpr (!PAR) {   // PAR: classes differ 4:2:2:1 in work and are laid out one after the other -- giving each XCD
                           // a contiguous range would put all the heavy tiles on two of the eight; keep the hardware's
                           // round-robin instead
@@ -375,6 +372,37 @@ conv_igemm_kernel(ConvP p) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_igemm_kernel(ConvP p) {
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Grouped form: independent convolutions that share one tile configuration (the 3x3 of every pyramid level of an RPN
+// / RetinaNet head, the FPN output convs, ...) as ONE grid. The small levels (a few dozen workgroups, latency-bound
+// on their own) ride in the shadow of the large ones. Table in device memory, built once per group by
+// mxdet_conv2d_grouped_plan; block0 is a multiple of 8 so the XCD-aware tile order of every item stays aligned.
+struct ConvG {
+  ConvP p;
+  int block0, nblocks;
+};
+
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int b = bid - table[lo].block0;
+  const int nb = table[lo].nblocks;
+  if (b >= nb) return;                      // alignment padding between items
+  const ConvP p = table[lo].p;
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false>(p, b, nb);
+}
+
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
 
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
@@ -526,4 +554,106 @@ extern "C" int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy
   p.relu = 0; p.res_up = 0;
   p.M = d->N * d->H * d->W;
   return launch<true>(p, as_stream(stream));
+}
+
+// ---- grouped convolutions -------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
+static void launch_grouped_cfg(const ConvG* table, int n, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((conv_igemm_grouped_kernel<BM, BN, WM, WN, NS, DGRAD>), dim3((unsigned)grid), dim3(64 * WM * WN),
+                     0, s, table, n);
+}
+
+static const int kGroupedTiles[4][2] = {{128, 64}, {128, 128}, {64, 128}, {64, 64}};   // cfg -> BM, BN
+
+extern "C" size_t mxdet_conv2d_grouped_table_bytes(int32_t n) { return n > 0 ? (size_t)n * sizeof(ConvG) : 0; }
+
+extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t n, int32_t kind, void* table_host,
+                                         size_t table_bytes, int32_t* cfg_out, int32_t* grid_out) {
+  clear_error();
+  MXDET_REQUIRE(items && n > 0 && table_host && cfg_out && grid_out, MXDET_EINVAL, "conv2d_grouped_plan: null pointer");
+  MXDET_REQUIRE(kind == 0 || kind == 1, MXDET_EINVAL, "conv2d_grouped_plan: kind must be 0 (forward) or 1 (dgrad)");
+  MXDET_REQUIRE(table_bytes >= (size_t)n * sizeof(ConvG), MXDET_EWORKSPACE, "conv2d_grouped_plan: table too small");
+  ConvG* t = (ConvG*)table_host;
+  long long t64 = 0, t128_max = 0;
+  int max_cols = 0, kmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const mxdet_conv_desc_t* d = &items[i].desc;
+    int rc = validate(d, "conv2d_grouped_plan");
+    if (rc) return rc;
+    ConvP& p = t[i].p;
+    memset(&t[i], 0, sizeof(ConvG));
+    MXDET_REQUIRE(items[i].src && items[i].filt && items[i].dst, MXDET_EINVAL, "conv2d_grouped_plan: item %d: null pointer", i);
+    if (kind == 0) {
+      MXDET_REQUIRE(d->Cin % 64 == 0 && d->Cout % 8 == 0, MXDET_ESHAPE, "conv2d_grouped_plan: item %d: Cin %% 64, Cout %% 8", i);
+      p.x = (const uint16_t*)items[i].src; p.w = (const uint16_t*)items[i].filt; p.bias = items[i].bias;
+      p.res = (const uint16_t*)items[i].residual; p.mask = nullptr; p.y = (uint16_t*)items[i].dst;
+      p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.C = d->Cin;
+      p.Hd = d->Ho; p.Wd = d->Wo; p.Ncols = d->Cout;
+      p.relu = d->relu; p.res_up = d->res_upsample;
+      p.M = d->N * d->Ho * d->Wo;
+    } else {
+      MXDET_REQUIRE(d->Cout % 64 == 0 && d->Cin % 8 == 0, MXDET_ESHAPE, "conv2d_grouped_plan: item %d: Cout %% 64, Cin %% 8", i);
+      MXDET_REQUIRE(d->stride == 1, MXDET_ESHAPE, "conv2d_grouped_plan: item %d: strided data gradients are not grouped", i);
+      MXDET_REQUIRE(!d->relu || items[i].relu_mask, MXDET_EINVAL, "conv2d_grouped_plan: item %d: relu without mask", i);
+      p.x = (const uint16_t*)items[i].src; p.w = (const uint16_t*)items[i].filt; p.bias = nullptr;
+      p.y = (uint16_t*)items[i].dst;
+      p.res = items[i].residual ? (const uint16_t*)items[i].residual : (d->accumulate ? (const uint16_t*)items[i].dst : nullptr);
+      p.mask = d->relu ? (const uint16_t*)items[i].relu_mask : nullptr;
+      p.N = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.C = d->Cout;
+      p.Hd = d->H; p.Wd = d->W; p.Ncols = d->Cin;
+      p.relu = 0; p.res_up = 0;
+      p.M = d->N * d->H * d->W;
+    }
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    t64 += (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 128);
+    long long t128 = (long long)ceil_div(p.M, 128) * ceil_div(p.Ncols, 128);
+    t128_max = t128 > t128_max ? t128 : t128_max;
+    max_cols = p.Ncols > max_cols ? p.Ncols : max_cols;
+    kmax = p.KH * p.KW * p.C > kmax ? p.KH * p.KW * p.C : kmax;
+  }
+  // one tile configuration for the whole group, by the same rule as single launches (on the group's totals)
+  int cfg;
+  if (max_cols <= 64) cfg = 0;
+  else if (t128_max >= 1536 && kmax > 256) cfg = 1;
+  else if (t64 >= 400) cfg = 2;
+  else cfg = 3;
+  const int BM = kGroupedTiles[cfg][0], BN = kGroupedTiles[cfg][1];
+  long long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvP& p = t[i].p;
+    p.tiles_m = ceil_div(p.M, BM);
+    p.tiles_n = ceil_div(p.Ncols, BN);
+    t[i].nblocks = p.tiles_m * p.tiles_n;
+    t[i].block0 = (int)blocks;
+    blocks += (long long)align_up((size_t)t[i].nblocks, 8);
+    MXDET_REQUIRE(blocks < (1ll << 30), MXDET_ESHAPE, "conv2d_grouped_plan: group too large");
+  }
+  *cfg_out = cfg;
+  *grid_out = (int32_t)blocks;
+  return MXDET_OK;
+}
+
+extern "C" int mxdet_conv2d_grouped(const void* table_dev, int32_t n, int32_t kind, int32_t cfg, int32_t grid,
+                                    mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(table_dev && n > 0 && grid > 0, MXDET_EINVAL, "conv2d_grouped: empty group");
+  MXDET_REQUIRE((kind == 0 || kind == 1) && cfg >= 0 && cfg <= 3, MXDET_EINVAL, "conv2d_grouped: bad kind / cfg");
+  const ConvG* t = (const ConvG*)table_dev;
+  hipStream_t s = as_stream(stream);
+  if (kind == 0) {
+    switch (cfg) {
+      case 0: launch_grouped_cfg<128, 64, 4, 1, 2, false>(t, n, grid, s); break;
+      case 1: launch_grouped_cfg<128, 128, 2, 2, 2, false>(t, n, grid, s); break;
+      case 2: launch_grouped_cfg<64, 128, 2, 2, 2, false>(t, n, grid, s); break;
+      default: launch_grouped_cfg<64, 64, 2, 2, 3, false>(t, n, grid, s); break;
+    }
+  } else {
+    switch (cfg) {
+      case 0: launch_grouped_cfg<128, 64, 4, 1, 2, true>(t, n, grid, s); break;
+      case 1: launch_grouped_cfg<128, 128, 2, 2, 2, true>(t, n, grid, s); break;
+      case 2: launch_grouped_cfg<64, 128, 2, 2, 2, true>(t, n, grid, s); break;
+      default: launch_grouped_cfg<64, 64, 2, 2, 3, true>(t, n, grid, s); break;
+    }
+  }
+  return check_launch("conv2d_grouped");
 }

@@ -49,7 +49,9 @@ class FPN:
             res = inner[i + 1] if i + 1 < L else None
             inner[i] = self.lats[i].forward(feats[i], residual=res, res_upsample=res is not None,
                                             out=self._buf("inner%d" % i, shape))
-        P = [self.outs[i].forward(inner[i], out=self._buf("P%d" % i, inner[i].shape)) for i in range(L)]
+        P = [self._buf("P%d" % i, inner[i].shape) for i in range(L)]
+        self.outs[0].forward(inner[0], out=P[0])          # the finest level fills the chip on its own
+        dense.conv2d_group("fwd", [self.outs[i].fwd_call(inner[i], out=P[i]) for i in range(1, L)], self.device)
         if self.extra_p6:
             N, H, W, Cc = P[-1].shape
             P.append(dense.subsample2(P[-1], self._buf("P6", (N, (H + 1) // 2, (W + 1) // 2, Cc))))
@@ -63,20 +65,23 @@ class FPN:
         L = self.L
         if self.extra_p6:
             dense.subsample2_backward(dP[L], dP[L - 1], accumulate=True)
-        dinner = [None] * L
+        dinner = [self._buf("dinner%d" % i, self.inner[i].shape) for i in range(L)]
         for i in range(L):
             self.outs[i].backward_weight(self.inner[i], dP[i])
-            dinner[i] = self.outs[i].backward_data(dP[i], self.inner[i].shape,
-                                                   out=self._buf("dinner%d" % i, self.inner[i].shape))
-            if i > 0:
-                dense.upsample2_backward(dinner[i - 1], dinner[i], accumulate=True)
+        self.outs[0].backward_data(dP[0], self.inner[0].shape, out=dinner[0])
+        dense.conv2d_group("dgrad", [self.outs[i].dgrad_call(dP[i], self.inner[i].shape, out=dinner[i])
+                                     for i in range(1, L)], self.device)
+        for i in range(1, L):                    # top-down path backwards: fine -> coarse, in order
+            dense.upsample2_backward(dinner[i - 1], dinner[i], accumulate=True)
+        calls = []
         for i in range(L):
             self.lats[i].backward_weight(self.feats[i], dinner[i])
             if c_needs_grad[i]:
                 top = i == L - 1
-                self.lats[i].backward_data(dinner[i], self.feats[i].shape, relu_mask=self.feats[i] if top else None,
-                                           out=dC[i])
-
+                calls.append(self.lats[i].dgrad_call(dinner[i], self.feats[i].shape,
+                                                     relu_mask=self.feats[i] if top else None, out=dC[i]))
+        if calls:
+            dense.conv2d_group("dgrad", calls, self.device)
 
 class RetinaFPN:
     """RetinaNet pyramid P3..P7: laterals + top-down on C3..C5, P6 = 3x3/2 conv on C5, P7 = 3x3/2 conv on ReLU(P6)

@@ -9,6 +9,7 @@ import torch
 
 from ...core import anchor as A_
 from ...core import loss as L_
+from ...ops import dense
 from ...ops.proposal import PyramidProposal
 from ..utils.layers import ConvLayer
 
@@ -65,13 +66,16 @@ class RPNHead:
         self.loss = torch.zeros((2,), dtype=torch.float32, device=self.device)
 
     def forward(self, P):
+        """The largest level keeps its own launches (it fills the chip and has its own tile path); the remaining levels
+        -- a few dozen to a few hundred workgroups each -- share one grouped launch per layer."""
         self.P = P
-        self.t, self.h = [], []
-        for l, p in enumerate(P):
-            t = self.conv.forward(p, relu=True, out=self._buf("t%d" % l, p.shape))
-            h = self.out.forward(t, out=self._buf("h%d" % l, p.shape[:3] + (HEAD_CPAD,)))
-            self.t.append(t)
-            self.h.append(h)
+        tb = [self._buf("t%d" % l, p.shape) for l, p in enumerate(P)]
+        hb = [self._buf("h%d" % l, p.shape[:3] + (HEAD_CPAD,)) for l, p in enumerate(P)]
+        self.conv.forward(P[0], relu=True, out=tb[0])
+        dense.conv2d_group("fwd", [self.conv.fwd_call(P[l], relu=True, out=tb[l]) for l in range(1, len(P))], self.device)
+        self.out.forward(tb[0], out=hb[0])
+        dense.conv2d_group("fwd", [self.out.fwd_call(tb[l], out=hb[l]) for l in range(1, len(P))], self.device)
+        self.t, self.h = tb, hb
         return self.h
 
     def get_proposals(self, im_info):
@@ -97,10 +101,15 @@ class RPNHead:
 
     def backward(self, dP, dP_has_grad):
         """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False)."""
-        for l in range(len(self.h)):
-            acc = l > 0
-            self.out.backward_weight(self.t[l], self.gh[l], accumulate=acc)
-            d_t = self.out.backward_data(self.gh[l], self.t[l].shape, relu_mask=self.t[l],
-                                         out=self._buf("dt%d" % l, self.t[l].shape))
-            self.conv.backward_weight(self.P[l], d_t, accumulate=acc)
-            self.conv.backward_data(d_t, self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])
+        L = len(self.h)
+        dt = [self._buf("dt%d" % l, self.t[l].shape) for l in range(L)]
+        for l in range(L):
+            self.out.backward_weight(self.t[l], self.gh[l], accumulate=l > 0)
+        self.out.backward_data(self.gh[0], self.t[0].shape, relu_mask=self.t[0], out=dt[0])
+        dense.conv2d_group("dgrad", [self.out.dgrad_call(self.gh[l], self.t[l].shape, relu_mask=self.t[l], out=dt[l])
+                                     for l in range(1, L)], self.device)
+        for l in range(L):
+            self.conv.backward_weight(self.P[l], dt[l], accumulate=l > 0)
+        self.conv.backward_data(dt[0], self.P[0].shape, accumulate=dP_has_grad[0], out=dP[0])
+        dense.conv2d_group("dgrad", [self.conv.dgrad_call(dt[l], self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])
+                                     for l in range(1, L)], self.device)

@@ -178,6 +178,14 @@ class ConvLayer:
         return dense.conv2d_forward(x, self.w_bf16, self.bias_f32, residual, self.stride, self.pad, relu, res_upsample,
                                     out)
 
+    def fwd_call(self, x, relu=False, residual=None, res_upsample=False, out=None):
+        """Argument tuple of this layer's forward for dense.conv2d_group("fwd", ...)."""
+        return (x, self.w_bf16, self.bias_f32, residual, self.stride, self.pad, relu, res_upsample, out)
+
+    def dgrad_call(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None):
+        """Argument tuple of this layer's data gradient for dense.conv2d_group("dgrad", ...)."""
+        return (dy, self.wt, tuple(x_shape), self.k, self.k, self.stride, self.pad, residual, relu_mask, accumulate, out)
+
     def backward_data(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None):
         return dense.conv2d_dgrad(dy, self.wt, x_shape, self.k, self.k, self.stride, self.pad, residual, relu_mask,
                                   accumulate, out)

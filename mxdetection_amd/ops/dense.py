@@ -66,6 +66,73 @@ def conv2d_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=Fa
     return dw
 
 
+class GroupedConv:
+    """Independent convolutions of one kind as ONE launch (mxdet_conv2d_grouped). kind "fwd": calls are the argument
+    tuples of conv2d_forward (x, w, bias, residual, stride, pad, relu, res_upsample, out); kind "dgrad": those of
+    conv2d_dgrad (dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out); `out` is required. The
+    plan holds device addresses: build it once in eager mode, relaunch while the tensors stay where they are."""
+
+    def __init__(self, kind, calls, device):
+        lib = _lib.load()
+        n = len(calls)
+        items = (_lib.ConvItemT * n)()
+        self.keep, self.kind = calls, 0 if kind == "fwd" else 1
+        self.flops = 0.0
+        dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        for it, c in zip(items, calls):
+            if self.kind == 0:
+                x, w, bias, residual, stride, pad, relu, res_up, out = c
+                N, H, W, Cin = x.shape
+                Cout, KH, KW, _ = w.shape
+                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_up)
+                it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = dp(x), dp(w), dp(bias), dp(residual), None, dp(out)
+                self.flops += 2.0 * N * it.desc.Ho * it.desc.Wo * Cout * KH * KW * Cin
+            else:
+                dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c
+                N, H, W, Cin = x_shape
+                Cout = dy.shape[3]
+                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate)
+                it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = dp(dy), dp(wt), None, dp(residual), dp(relu_mask), dp(out)
+                self.flops += 2.0 * N * dy.shape[1] * dy.shape[2] * Cout * KH * KW * Cin
+        nbytes = lib.mxdet_conv2d_grouped_table_bytes(n)
+        host = (C.c_ubyte * nbytes)()
+        cfg, grid = C.c_int32(0), C.c_int32(0)
+        check(lib.mxdet_conv2d_grouped_plan(items, n, self.kind, host, nbytes, C.byref(cfg), C.byref(grid)),
+              "conv2d_grouped_plan")
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
+        self.n, self.cfg, self.grid = n, cfg.value, grid.value
+
+    def launch(self):
+        check(_lib.load().mxdet_conv2d_grouped(ptr(self.table), self.n, self.kind, self.cfg, self.grid, stream_ptr()),
+              "conv2d_grouped")
+
+
+_group_plans = {}
+
+
+def conv2d_group(kind, calls, device):
+    """Run `calls` (see GroupedConv) as one grouped launch; plans are cached by the tensors' addresses. Under stream
+    capture an unseen group cannot upload its table: it falls back to one launch per call (same results)."""
+    if len(calls) == 1:
+        plan = None
+    else:
+        key = (kind,) + tuple(tuple(t.data_ptr() if torch.is_tensor(t) else t for t in c) for c in calls)
+        plan = _group_plans.get(key)
+        if plan is None and not torch.cuda.is_current_stream_capturing():
+            plan = GroupedConv(kind, calls, device)
+            _group_plans[key] = plan
+    if plan is not None:
+        plan.launch()
+        return
+    for c in calls:
+        if kind == "fwd":
+            x, w, bias, residual, stride, pad, relu, res_up, out = c
+            conv2d_forward(x, w, bias, residual, stride, pad, relu, res_up, out)
+        else:
+            dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c
+            conv2d_dgrad(dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out)
+
+
 class GroupedWgrad:
     """Weight gradients of several layers as one launch pair (mxdet_conv2d_wgrad_grouped). `calls` is a list of
     (x, dy, KH, KW, stride, pad, dw, db, accumulate); the plan (device table, grids, workspace size) is built once, in
