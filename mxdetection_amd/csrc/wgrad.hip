@@ -36,6 +36,7 @@ struct WgradP {
   float* dw;           // [Cout][KH*KW*Cin]
   float* db;           // [Cout] or null
   int accumulate;
+  int force_slab;      // grouped form, filters shared by several items: always write slabs (the owner folds them all)
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
   int M;               // N*Ho*Wo
   int co_tiles, ci_tiles, ksplit, steps_per_split;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) t += red[r * 128 + tid];
       const int c = co_t * 128 + tid;
-      if (p.ksplit == 1) p.db[c] = p.accumulate ? p.db[c] + t : t;
+      if (p.ksplit == 1 && !p.force_slab) p.db[c] = p.accumulate ? p.db[c] + t : t;
       else p.bslab[(size_t)ks * p.Cout + c] = t;
     }
     return;
@@ -274,7 +275,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b) {
 
   // D layout: col = lane&15 -> ci, row = (lane>>4)*4 + r -> co
   const size_t Ktot = (size_t)p.KH * p.KW * p.Cin;
-  const bool single = p.ksplit == 1;
+  const bool single = p.ksplit == 1 && !p.force_slab;
   // one split: the tile goes straight to dw/db; otherwise to this split's slab
   float* out = single ? p.dw : p.slab + (size_t)ks * p.Cout * Ktot;
   const bool add_old = single && p.accumulate;
@@ -310,7 +311,7 @@ struct WgradG {
   WgradP p;                 // slab / bslab hold byte offsets into the workspace
   int block0, nblocks;      // this layer's workgroups: [block0, block0 + nblocks), block0 a multiple of 8
   int rblock0, wblocks, bblocks;   // fold kernel: first workgroup, workgroups over dw, workgroups over db
-  int pad_;
+  int fold_ksplit;                 // slabs the fold adds up (all items that share this item's dw write into one run)
   long long nparams;
 };
 
@@ -382,8 +383,8 @@ wgrad_reduce_grouped_kernel(const WgradG* __restrict__ table, int n, const unsig
   }
   const WgradG& g = table[lo];
   const int b = bid - g.rblock0;
-  const int ksplit = g.p.ksplit, Cout = g.p.Cout, accumulate = g.p.accumulate;
-  if (ksplit <= 1 || b >= g.wblocks + g.bblocks) return;      // single-split layers wrote dw / db directly
+  const int ksplit = g.fold_ksplit, Cout = g.p.Cout, accumulate = g.p.accumulate;
+  if (b >= g.wblocks + g.bblocks) return;      // nothing to fold (single split: dw / db written directly; or not the owner)
   const float* slab = (const float*)(workspace + (size_t)g.p.slab);
   const float* bslab = (const float*)(workspace + (size_t)g.p.bslab);
   float* dw = g.p.dw;
@@ -548,7 +549,7 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
   WgradP p;
   p.x = x; p.dy = dy; p.slab = (float*)workspace;
   p.bslab = (float*)((char*)workspace + w.bslab_off);
-  p.dw = dw; p.db = db; p.accumulate = d->accumulate;
+  p.dw = dw; p.db = db; p.accumulate = d->accumulate; p.force_slab = 0;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
   p.M = d->N * d->Ho * d->Wo;
@@ -639,19 +640,49 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
     p.ksplit = ceil_div(steps, p.steps_per_split);
     const size_t params = (size_t)d->Cout * taps * d->Cin;
     g.nparams = (long long)params;
-    p.slab = (float*)off;                                    // byte offsets; resolved against the workspace at launch
-    off += align_up((size_t)p.ksplit * params * sizeof(float), 256);
-    p.bslab = (float*)off;
-    off += align_up((size_t)p.ksplit * d->Cout * sizeof(float), 256);
     p.nwg_main = (int)(tiles * p.ksplit);
     g.nblocks = p.nwg_main + (p.db ? p.co_tiles * p.ksplit : 0);
     g.block0 = (int)blocks;
     blocks += align_up((size_t)g.nblocks, 8);
-    g.wblocks = p.ksplit > 1 ? (int)ceil_div<long long>((long long)params / 4, 256) : 0;
-    g.bblocks = (p.ksplit > 1 && p.db) ? ceil_div(d->Cout, 256) : 0;
-    g.rblock0 = (int)rblocks;
-    rblocks += g.wblocks + g.bblocks;
-    MXDET_REQUIRE(blocks < (1ll << 30) && rblocks < (1ll << 30), MXDET_ESHAPE, "wgrad_grouped_plan: group too large");
+    MXDET_REQUIRE(blocks < (1ll << 30), MXDET_ESHAPE, "wgrad_grouped_plan: group too large");
+  }
+  // slabs: items that share dw (one filter applied at several pyramid levels) write into one run of slabs that the
+  // first of them (the owner) folds; everything else owns its run
+  for (int i = 0; i < n; ++i) {
+    int owner = i;
+    for (int j = 0; j < i; ++j)
+      if (items[j].dw == items[i].dw) { owner = j; break; }
+    if (owner != i) continue;
+    int total_ks = 0, members = 0;
+    for (int j = i; j < n; ++j)
+      if (items[j].dw == items[i].dw) { total_ks += t[j].p.ksplit; ++members; }
+    const size_t params = (size_t)t[i].nparams, cout = (size_t)t[i].p.Cout;
+    const size_t slab0 = off;
+    off += align_up((size_t)total_ks * params * sizeof(float), 256);
+    const size_t bslab0 = off;
+    off += align_up((size_t)total_ks * cout * sizeof(float), 256);
+    int ks0 = 0;
+    for (int j = i; j < n; ++j) {
+      if (items[j].dw != items[i].dw) continue;
+      MXDET_REQUIRE((size_t)t[j].nparams == params && items[j].db == items[i].db, MXDET_ESHAPE,
+                    "wgrad_grouped_plan: items %d and %d share dw but differ in shape or db", i, j);
+      t[j].p.slab = (float*)(slab0 + (size_t)ks0 * params * sizeof(float));
+      t[j].p.bslab = (float*)(bslab0 + (size_t)ks0 * cout * sizeof(float));
+      t[j].p.force_slab = members > 1 ? 1 : 0;
+      ks0 += t[j].p.ksplit;
+    }
+    WgradG& g = t[i];
+    g.fold_ksplit = total_ks;
+    const bool fold = members > 1 || g.p.ksplit > 1;
+    g.wblocks = fold ? (int)ceil_div<long long>((long long)params / 4, 256) : 0;
+    g.bblocks = (fold && g.p.db) ? ceil_div((int)cout, 256) : 0;
+    // the owner's fold reads from the start of the run
+    g.rblock0 = 0;
+  }
+  for (int i = 0; i < n; ++i) {
+    t[i].rblock0 = (int)rblocks;
+    rblocks += t[i].wblocks + t[i].bblocks;
+    MXDET_REQUIRE(rblocks < (1ll << 30), MXDET_ESHAPE, "wgrad_grouped_plan: group too large");
   }
   *workspace_bytes = off;
   *grid_wgrad = (int32_t)blocks;

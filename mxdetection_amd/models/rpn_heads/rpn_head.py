@@ -103,13 +103,15 @@ class RPNHead:
         """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False)."""
         L = len(self.h)
         dt = [self._buf("dt%d" % l, self.t[l].shape) for l in range(L)]
+        grouped = self.out.ws.grouping     # grouped form: the plan sums the levels of a shared filter itself
         for l in range(L):
-            self.out.backward_weight(self.t[l], self.gh[l], accumulate=l > 0)
+            self.out.backward_weight(self.t[l], self.gh[l], accumulate=(l > 0) and not grouped)
         self.out.backward_data(self.gh[0], self.t[0].shape, relu_mask=self.t[0], out=dt[0])
         dense.conv2d_group("dgrad", [self.out.dgrad_call(self.gh[l], self.t[l].shape, relu_mask=self.t[l], out=dt[l])
                                      for l in range(1, L)], self.device)
         for l in range(L):
-            self.conv.backward_weight(self.P[l], dt[l], accumulate=l > 0)
+            self.conv.backward_weight(self.P[l], dt[l], accumulate=(l > 0) and not grouped)
         self.conv.backward_data(dt[0], self.P[0].shape, accumulate=dP_has_grad[0], out=dP[0])
         dense.conv2d_group("dgrad", [self.conv.dgrad_call(dt[l], self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])
                                      for l in range(1, L)], self.device)
+        self.out.ws.flush()

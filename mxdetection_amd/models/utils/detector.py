@@ -190,6 +190,8 @@ class DetectorBase:
     def enable_grouped_wgrad(self):
         """Issue the weight gradients of each bucket (box/mask heads, FPN, every ResNet stage) as one grouped launch."""
         self.ws.grouping = True
+        if getattr(self, "ws_rpn", None) is not None:
+            self.ws_rpn.grouping = True
 
     def _reduce(self, lo, hi):
         self.ws.flush()           # grouped mode: the bucket's recorded weight gradients go out now

@@ -15,6 +15,7 @@ def main():
     timer = bench.ConvTimer()
     timer.install()
     m = FasterRCNN("cuda", seed=7)
+    m.enable_grouped_wgrad()
     batch = bench.synth_batch(0, 0, "cuda")
     for i in range(2):
         m.train_step(*batch, step=i, lr=1e-4)
@@ -26,7 +27,11 @@ def main():
     REPS = 8
     for family, flops, fn, a, kw in timer.log:
         t = bench.ConvTimer.time_launch(fn, a, kw, REPS)
-        if family == "conv_igemm_fwd":
+        plan = a[0] if a and hasattr(a[0], "grid") or (a and hasattr(a[0], "grid_wgrad")) else None
+        if plan is not None:     # grouped launch: (layers in the group, -, -, 0, 0)
+            key = (plan.n, 0, 0, 0, 0)
+            family = family + "_grouped"
+        elif family == "conv_igemm_fwd":
             x, w = a[0], a[1]
             stride = kw.get("stride", a[4] if len(a) > 4 else 1)
             key = (x.shape[0] * ((x.shape[1] - 1) // stride + 1) * ((x.shape[2] - 1) // stride + 1), w.shape[0],
@@ -37,15 +42,16 @@ def main():
         else:
             x, dy = a[0], a[1]
             key = (dy.shape[3], a[2] * a[3] * x.shape[3], dy.shape[0] * dy.shape[1] * dy.shape[2], a[2], a[4] if len(a) > 4 else kw.get("stride", 1))
-        r = agg.setdefault((family[5:], key), [0.0, 0, 0.0])
+        r = agg.setdefault((family[5:] + ("" if plan is None else "#%d" % id(plan)), key), [0.0, 0, 0.0])
         r[0] += t
         r[1] += 1
         r[2] += flops
     tot = sum(v[0] for v in agg.values())
+    print("grouped launches: M column = number of layers in the group")
     print("%-11s %8s %6s %7s k s  %4s %9s %8s %6s" % ("family", "M", "N", "K", "n", "avg_us", "TFLOP/s", "share"))
     for (fam, key), (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         M, Nn, K, k, s = key
-        print("%-11s %8d %6d %7d %d %d  %4d %9.1f %8.1f %5.1f%%" % (fam, M, Nn, K, k, s, n, 1e6 * t / n, fl / t / 1e12, 100 * t / tot))
+        print("%-11s %8d %6d %7d %d %d  %4d %9.1f %8.1f %5.1f%%" % (fam.split("#")[0][:20], M, Nn, K, k, s, n, 1e6 * t / n, fl / t / 1e12, 100 * t / tot))
     print("conv total per step: %.3f ms" % (1e3 * tot))
 
 
