@@ -251,3 +251,55 @@ def test_sgd_momentum(hip):
     w_ref = w0 - 0.02 * m_ref
     assert torch.allclose(m, m_ref, rtol=1e-6, atol=1e-7) and torch.allclose(w, w_ref, rtol=1e-6, atol=1e-7)
     assert torch.equal(wb, w.to(torch.bfloat16))
+
+
+def test_grouped_conv_and_wgrad_match_single_launches(hip, oracle):
+    """mxdet_conv2d_grouped / mxdet_conv2d_wgrad_grouped against the single-layer entry points on a small pyramid:
+    forward and data gradients must be bit-identical (same kernel body, same tiles); weight gradients equal up to the
+    split-K partition; items that share dw (one filter at several levels) are summed."""
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(21)
+    shapes = [(2, 25, 42), (2, 13, 21), (2, 7, 11)]
+    Cin, Cout, K = 64, 128, 3
+    w = _t(_bf(rng, (Cout, K, K, Cin), 0.05, oracle), torch.bfloat16)
+    wt = dense.filter_transpose(w)
+    bias = _t(rng.standard_normal(Cout).astype(np.float32))
+    xs = [_t(_bf(rng, s + (Cin,), 1.0, oracle), torch.bfloat16) for s in shapes]
+    dys = [_t(_bf(rng, s + (Cout,), 1.0, oracle), torch.bfloat16) for s in shapes]
+    # forward
+    ref = [dense.conv2d_forward(x, w, bias, None, 1, 1, True) for x in xs]
+    outs = [torch.empty_like(r) for r in ref]
+    dense.conv2d_group("fwd", [(x, w, bias, None, 1, 1, True, False, o) for x, o in zip(xs, outs)], "cuda")
+    for r, o in zip(ref, outs):
+        assert torch.equal(r, o)
+    # data gradient with a ReLU mask
+    refd = [dense.conv2d_dgrad(dy, wt, tuple(x.shape), K, K, 1, 1, relu_mask=x) for dy, x in zip(dys, xs)]
+    outd = [torch.empty_like(r) for r in refd]
+    dense.conv2d_group("dgrad", [(dy, wt, tuple(x.shape), K, K, 1, 1, None, x, False, o)
+                                 for dy, x, o in zip(dys, xs, outd)], "cuda")
+    for r, o in zip(refd, outd):
+        assert torch.equal(r, o)
+    # weight gradients: independent filters ...
+    dws = [torch.empty((Cout, K, K, Cin), device="cuda") for _ in shapes]
+    dbs = [torch.empty((Cout,), device="cuda") for _ in shapes]
+    plan = dense.GroupedWgrad([(x, dy, K, K, 1, 1, dw, db, False) for x, dy, dw, db in zip(xs, dys, dws, dbs)], "cuda")
+    ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
+    plan.launch(ws)
+    one = []
+    for x, dy, dw, db in zip(xs, dys, dws, dbs):
+        rdw, rdb = torch.empty_like(dw), torch.empty_like(db)
+        dense.conv2d_wgrad(x, dy, K, K, 1, 1, dw=rdw, db=rdb)
+        one.append((rdw, rdb))
+        _close(dw.cpu().numpy(), rdw.cpu().numpy(), "grouped wgrad")
+        _close(db.cpu().numpy(), rdb.cpu().numpy(), "grouped bias grad")
+    # ... and one filter shared by all levels: the group sums the levels
+    dw_s, db_s = torch.empty((Cout, K, K, Cin), device="cuda"), torch.empty((Cout,), device="cuda")
+    plan = dense.GroupedWgrad([(x, dy, K, K, 1, 1, dw_s, db_s, False) for x, dy in zip(xs, dys)], "cuda")
+    ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
+    plan.launch(ws)
+    _close(dw_s.cpu().numpy(), sum(o[0] for o in one).cpu().numpy(), "shared-filter wgrad")
+    _close(db_s.cpu().numpy(), sum(o[1] for o in one).cpu().numpy(), "shared-filter bias grad")
+    # strided data gradients are refused by the grouped plan (they have their own parity-grouped kernel)
+    with pytest.raises(hip.MxdetError):
+        dense.GroupedConv("dgrad", [(dys[1], wt, (2, 25, 42, Cin), K, K, 2, 1, None, None, False, outd[0])] * 2, "cuda")
