@@ -11,6 +11,7 @@ import torch
 
 from ...core import anchor as A_
 from ...core import loss as L_
+from ...ops import dense
 from ..utils.layers import ConvLayer
 
 
@@ -75,21 +76,26 @@ class RetinaHead:
         self.loss = torch.zeros((2,), dtype=torch.float32, device=dev)
 
     def forward(self, P):
+        """Layer i of BOTH towers on ALL levels is one grouped launch (10 independent convolutions): 5 launches for the
+        whole head instead of 50; the small levels ride in the shadow of P3."""
         self.P = P
-        self.cact, self.bact, self.co, self.bo = [], [], [], []
-        for l, p in enumerate(P):
-            x, acts = p, [p]
-            for i, c in enumerate(self.cls_convs):
-                x = c.forward(x, relu=True, out=self._buf("c%d_%d" % (l, i), p.shape))
-                acts.append(x)
-            self.cact.append(acts)
-            self.co.append(self.cls_out.forward(x, out=self._buf("co%d" % l, p.shape[:3] + (self.ld_cls,))))
-            x, acts = p, [p]
-            for i, c in enumerate(self.box_convs):
-                x = c.forward(x, relu=True, out=self._buf("b%d_%d" % (l, i), p.shape))
-                acts.append(x)
-            self.bact.append(acts)
-            self.bo.append(self.box_out.forward(x, out=self._buf("bo%d" % l, p.shape[:3] + (self.ld_reg,))))
+        L, n = len(P), len(self.cls_convs)
+        self.cact = [[p] for p in P]
+        self.bact = [[p] for p in P]
+        for i in range(n):
+            calls = []
+            for l, p in enumerate(P):
+                co = self._buf("c%d_%d" % (l, i), p.shape)
+                bo = self._buf("b%d_%d" % (l, i), p.shape)
+                calls.append(self.cls_convs[i].fwd_call(self.cact[l][-1], relu=True, out=co))
+                calls.append(self.box_convs[i].fwd_call(self.bact[l][-1], relu=True, out=bo))
+                self.cact[l].append(co)
+                self.bact[l].append(bo)
+            dense.conv2d_group("fwd", calls, self.device)
+        self.co = [self._buf("co%d" % l, p.shape[:3] + (self.ld_cls,)) for l, p in enumerate(P)]
+        self.bo = [self._buf("bo%d" % l, p.shape[:3] + (self.ld_reg,)) for l, p in enumerate(P)]
+        dense.conv2d_group("fwd", [self.cls_out.fwd_call(self.cact[l][-1], out=self.co[l]) for l in range(L)] +
+                           [self.box_out.fwd_call(self.bact[l][-1], out=self.bo[l]) for l in range(L)], self.device)
         return self.co, self.bo
 
     def loss_and_grad(self, gt_boxes, im_info, loss_scale=1.0):
@@ -110,19 +116,38 @@ class RetinaHead:
         return self.loss
 
     def backward(self, dP):
-        """Writes d(loss)/d(P_l) into dP[l] (overwrites)."""
-        n = len(self.cls_convs)
-        for l in range(len(self.co)):
-            acc = l > 0
-            for out_layer, convs, acts, g, key, first in ((self.cls_out, self.cls_convs, self.cact[l], self.gco[l], "c", True),
-                                                          (self.box_out, self.box_convs, self.bact[l], self.gbo[l], "b", False)):
-                x = acts[-1]
-                out_layer.backward_weight(x, g, accumulate=acc)
-                d = out_layer.backward_data(g, x.shape, relu_mask=x, out=self._buf("d%s%d_%d" % (key, l, n), x.shape))
-                for i in reversed(range(n)):
-                    xin = acts[i]
-                    convs[i].backward_weight(xin, d, accumulate=acc)
-                    if i > 0:
-                        d = convs[i].backward_data(d, xin.shape, relu_mask=xin, out=self._buf("d%s%d_%d" % (key, l, i), xin.shape))
-                    else:   # into the pyramid gradient: class tower writes, box tower adds
-                        convs[i].backward_data(d, xin.shape, accumulate=not first, out=dP[l])
+        """Writes d(loss)/d(P_l) into dP[l] (overwrites). Same grouping as forward; weight gradients of a filter are
+        summed over the levels (by the grouped plan when the workspace groups, by accumulate flags otherwise)."""
+        n, L = len(self.cls_convs), len(self.co)
+        grouped = self.cls_out.ws.grouping
+        dbuf = lambda key, l, i, shape: self._buf("d%s%d_%d" % (key, l, i), shape)   # noqa: E731
+        dc = [None] * L
+        db = [None] * L
+        calls = []
+        for l in range(L):
+            xc, xb = self.cact[l][-1], self.bact[l][-1]
+            self.cls_out.backward_weight(xc, self.gco[l], accumulate=(l > 0) and not grouped)
+            self.box_out.backward_weight(xb, self.gbo[l], accumulate=(l > 0) and not grouped)
+            dc[l], db[l] = dbuf("c", l, n, xc.shape), dbuf("b", l, n, xb.shape)
+            calls.append(self.cls_out.dgrad_call(self.gco[l], xc.shape, relu_mask=xc, out=dc[l]))
+            calls.append(self.box_out.dgrad_call(self.gbo[l], xb.shape, relu_mask=xb, out=db[l]))
+        dense.conv2d_group("dgrad", calls, self.device)
+        for i in reversed(range(n)):
+            calls_c, calls_b = [], []
+            for l in range(L):
+                xc, xb = self.cact[l][i], self.bact[l][i]
+                self.cls_convs[i].backward_weight(xc, dc[l], accumulate=(l > 0) and not grouped)
+                self.box_convs[i].backward_weight(xb, db[l], accumulate=(l > 0) and not grouped)
+                if i > 0:
+                    nc, nb = dbuf("c", l, i, xc.shape), dbuf("b", l, i, xb.shape)
+                    calls_c.append(self.cls_convs[i].dgrad_call(dc[l], xc.shape, relu_mask=xc, out=nc))
+                    calls_b.append(self.box_convs[i].dgrad_call(db[l], xb.shape, relu_mask=xb, out=nb))
+                    dc[l], db[l] = nc, nb
+                else:   # into the pyramid gradient: the class tower writes, then the box tower adds
+                    calls_c.append(self.cls_convs[i].dgrad_call(dc[l], xc.shape, out=dP[l]))
+                    calls_b.append(self.box_convs[i].dgrad_call(db[l], xb.shape, accumulate=True, out=dP[l]))
+            if i > 0:
+                dense.conv2d_group("dgrad", calls_c + calls_b, self.device)
+            else:
+                dense.conv2d_group("dgrad", calls_c, self.device)
+                dense.conv2d_group("dgrad", calls_b, self.device)
