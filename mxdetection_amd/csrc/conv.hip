@@ -296,8 +296,59 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   constexpr int RPP = 64 / LPR;         // rows per pass
   constexpr int PASSES = 32 / RPP;
   const int rl = lane / LPR, cg = lane - rl * LPR;
+  // bias: one pair of loads per lane for the whole epilogue (the column does not depend on the pass)
+  const int col = n0 + wn * WTN + cg * 8;
+  const bool colok = col < p.Ncols;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (p.bias) {
+    const int cb = colok ? col : 0;
+    b0 = *(const float4*)(p.bias + cb);
+    b1 = *(const float4*)(p.bias + cb + 4);
+  }
 #pragma unroll
   for (int h = 0; h < MT / 2; ++h) {
+    // Residual / mask operands of ALL passes of this half are fetched first, unconditionally (rows outside the
+    // tensor read element 0): a load inside the per-row `if` makes hipcc branch around it and wait for each one
+    // separately -- PASSES dependent round trips per half, most of the run time of a short-K 1x1 layer.
+    size_t pixs[PASSES];
+    bool oks[PASSES];
+    uint4 rres[PASSES], rmsk[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = ps * RPP + rl;
+      const int m = m0 + wm * WTM + h * 32 + row;
+      bool rowok = m < p.M;
+      size_t pix = (size_t)m;          // linear output pixel of this row
+      if constexpr (PAR) {
+        rowok = m < par_rows;
+        int img = m / (par_hc * par_wc);
+        int rem = m - img * (par_hc * par_wc);
+        int ih = rem / par_wc, iw = rem - ih * par_wc;
+        pix = (size_t)(img * p.Hd + p.par_h0[par_ph] + 2 * ih) * p.Wd + (p.par_w0[par_pw] + 2 * iw);
+      }
+      oks[ps] = rowok && colok;
+      pixs[ps] = oks[ps] ? pix : 0;
+    }
+    if (p.res) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        size_t ri = pixs[ps] * p.Ncols + (oks[ps] ? col : 0);
+        if (p.res_up) {
+          const int m = (int)pixs[ps];
+          int img = m / (p.Hd * p.Wd);
+          int rem = m - img * (p.Hd * p.Wd);
+          int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+          int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
+          ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * p.Ncols + (oks[ps] ? col : 0);
+        }
+        rres[ps] = *(const uint4*)(p.res + ri);
+      }
+    }
+    if (p.mask) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps)
+        rmsk[ps] = *(const uint4*)(p.mask + pixs[ps] * p.Ncols + (oks[ps] ? col : 0));
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -308,66 +359,37 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     // wave-private staging: the LDS ops of one wave execute in order, no barrier needed
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      int row = ps * RPP + rl;
-      int m = m0 + wm * WTM + h * 32 + row;
-      int col = n0 + wn * WTN + cg * 8;
+      const int row = ps * RPP + rl;
       float4 v0 = *(const float4*)(ep + row * EP_STRIDE + cg * 8);
       float4 v1 = *(const float4*)(ep + row * EP_STRIDE + cg * 8 + 4);
-      bool rowok = m < p.M;
-      size_t pix = (size_t)m;          // linear output pixel of this row
-      if constexpr (PAR) {
-        rowok = m < par_rows;
-        int img = m / (par_hc * par_wc);
-        int rem = m - img * (par_hc * par_wc);
-        int ih = rem / par_wc, iw = rem - ih * par_wc;
-        pix = (size_t)(img * p.Hd + p.par_h0[par_ph] + 2 * ih) * p.Wd + (p.par_w0[par_pw] + 2 * iw);
+      float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+      if (p.res) {
+        const uint4 rv = rres[ps];
+        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        v[4] += __uint_as_float(rv.z << 16); v[5] += __uint_as_float(rv.z & 0xffff0000u);
+        v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
       }
-      if (rowok && col < p.Ncols) {
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        if (p.bias) {
-          float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (p.res) {
-          size_t ri;
-          if (p.res_up) {
-            int img = m / (p.Hd * p.Wd);
-            int rem = m - img * (p.Hd * p.Wd);
-            int hd = rem / p.Wd, wd = rem - hd * p.Wd;
-            int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
-            ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * p.Ncols + col;
-          } else {
-            ri = pix * p.Ncols + col;
-          }
-          uint4 rv = *(const uint4*)(p.res + ri);
-          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-          v[4] += __uint_as_float(rv.z << 16); v[5] += __uint_as_float(rv.z & 0xffff0000u);
-          v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
-        }
-        if (p.mask) {
-          uint4 mv = *(const uint4*)(p.mask + pix * p.Ncols + col);
-          // bf16 > 0  <=>  sign clear and magnitude non-zero
-          unsigned mm[4] = {mv.x, mv.y, mv.z, mv.w};
+      if (p.mask) {
+        // bf16 > 0  <=>  sign clear and magnitude non-zero
+        const unsigned mm[4] = {rmsk[ps].x, rmsk[ps].y, rmsk[ps].z, rmsk[ps].w};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            unsigned lo = mm[k] & 0xffffu, hi = mm[k] >> 16;
-            if (!(lo != 0u && lo < 0x8000u)) v[2 * k] = 0.0f;
-            if (!(hi != 0u && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
-          }
+        for (int k = 0; k < 4; ++k) {
+          unsigned lo = mm[k] & 0xffffu, hi = mm[k] >> 16;
+          if (!(lo != 0u && lo < 0x8000u)) v[2 * k] = 0.0f;
+          if (!(hi != 0u && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
         }
-        if (p.relu && !p.mask) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
-        }
-        uint4 o;
-        o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-        o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-        o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
-        o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
-        *(uint4*)(p.y + pix * p.Ncols + col) = o;
       }
+      if (p.relu && !p.mask) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+      }
+      uint4 o;
+      o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+      o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+      o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+      o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+      if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
     }
   }
 }
