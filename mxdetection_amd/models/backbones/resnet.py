@@ -48,10 +48,18 @@ class Bottleneck:
 
     def forward(self, x):
         self.x = x
-        self.a1 = self.conv1.forward(x, relu=True, out=self._buf("a1", self.conv1.out_shape(x.shape)))
-        self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", self.conv2.out_shape(self.a1.shape)))
-        oshape = self.conv3.out_shape(self.a2.shape)
-        sc = x if self.down is None else self.down.forward(x, out=self._buf("sc", oshape))
+        a1 = self._buf("a1", self.conv1.out_shape(x.shape))
+        s2 = self.conv2.out_shape(a1.shape)
+        oshape = self.conv3.out_shape(s2)
+        if self.down is None:
+            self.a1 = self.conv1.forward(x, relu=True, out=a1)
+            sc = x
+        else:       # conv1 and the projection shortcut read the same x: one grouped launch
+            sc = self._buf("sc", oshape)
+            dense.conv2d_group("fwd", [self.conv1.fwd_call(x, relu=True, out=a1), self.down.fwd_call(x, out=sc)],
+                               self.conv1.device)
+            self.a1 = a1
+        self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", s2))
         self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape))
         return self.y
 

@@ -104,6 +104,7 @@ def test_gradient_exchange_path_matches_single_gpu_step(hip):
         m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
         m.enable_wgrad_stream()
         m.enable_branch_stream()
+        m.enable_grouped_wgrad()
         if parallel:
             m.enable_data_parallel(1)
         w0 = m.arena.w.clone()
