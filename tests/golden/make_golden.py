@@ -54,6 +54,16 @@ def main():
     lv = rng.integers(3, 5, 20).astype(np.int32)
     d.update(ra_f0=feats[0], ra_f1=feats[1], ra_rois=rr, ra_levels=lv,
              ra_out=O.roi_align(feats, [1 / 8, 1 / 16], rr, lv, 7, 7, 2, 3))
+    # test-time post-processing (core/evaluation): 2 images x 40 rois x 7 classes, bf16-valued head outputs
+    R, Cn = 40, 7
+    pp_rois = np.zeros((2 * R, 5), np.float32)
+    pp_rois[:, 0] = np.repeat(np.arange(2), R)
+    pp_rois[:, 1:] = np.concatenate([synth_boxes(rng, R, 96, 128) for _ in range(2)])
+    pp_cls = O.round_bf16((rng.standard_normal((2 * R, Cn)) * 2.0).astype(np.float32))
+    pp_reg = O.round_bf16((rng.standard_normal((2 * R, 4 * Cn)) * 0.5).astype(np.float32))
+    dets, num, _, _ = O.detection_postprocess(pp_cls, pp_reg, pp_rois, [40, 33], info, (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2),
+                                              0.05, 0.5, 20)
+    d.update(pp_rois=pp_rois, pp_cls=pp_cls, pp_reg=pp_reg, pp_dets=dets, pp_num=num)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "det_small.npz"), **d)
     print("wrote det_small.npz with", len(d), "arrays")
 

@@ -48,3 +48,11 @@ def test_roi_align_golden(oracle):
     const = [np.full_like(G["ra_f0"], 0x4040), np.full_like(G["ra_f1"], 0x4040)]   # bf16 3.0
     out = oracle.roi_align(const, [1 / 8, 1 / 16], [[0, 10, 10, 60, 50]], [3], 7, 7, 2, 3)
     assert np.all(out == 0x4040)
+
+
+def test_detection_postprocess_golden(oracle):
+    g = G
+    dets, num, _, _ = oracle.detection_postprocess(g["pp_cls"], g["pp_reg"], g["pp_rois"], [40, 33], g["prop_info"],
+                                                   (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2), 0.05, 0.5, 20)
+    assert np.array_equal(num, g["pp_num"]) and np.array_equal(dets.view(np.uint32), g["pp_dets"].view(np.uint32))
+    assert g["pp_num"].min() >= 10

@@ -86,3 +86,19 @@ def test_faster_rcnn_predict_runs(hip):
     for n in range(2):
         assert np.all(d[n, :, 5] >= 1) and np.all(np.diff(d[n, :, 4]) <= 0)          # foreground classes, sorted by score
         assert np.all(d[n, :, 0] >= 0) and np.all(d[n, :, 2] <= 255) and np.all(d[n, :, 3] <= 191)
+
+
+def test_detection_postprocess_matches_committed_golden(hip):
+    """The HIP path against the committed fixture (tests/golden/det_small.npz, pp_*), bit for bit."""
+    import os
+    import torch
+    from mxdetection_amd.core.evaluation import DetectionPostprocess
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "det_small.npz"))
+    Cn = g["pp_cls"].shape[1]
+    post = DetectionPostprocess(Cn, score_thresh=0.05, nms_thresh=0.5, max_per_image=20, stds=(0.1, 0.1, 0.2, 0.2))
+    dets, num = post(torch.from_numpy(g["pp_cls"]).cuda(), torch.from_numpy(g["pp_reg"]).cuda(),
+                     torch.from_numpy(g["pp_rois"]).cuda(), torch.tensor([40, 33], dtype=torch.int32).cuda(),
+                     torch.from_numpy(g["prop_info"]).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(num.cpu().numpy(), g["pp_num"])
+    assert np.array_equal(dets.cpu().numpy().view(np.uint32), g["pp_dets"].view(np.uint32))
