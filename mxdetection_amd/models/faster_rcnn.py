@@ -70,7 +70,13 @@ class FasterRCNN(DetectorBase):
             self.mask_head.plan(N)
         self.ws.get()
         self.ws_rpn.get()
-        self.dP = [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in p_shapes]
+        # one flat bf16 buffer (levels are views, finest first): the RoI extractor finalizes P2..P5 with one launch
+        sizes = [s[0] * s[1] * s[2] * s[3] for s in p_shapes]
+        self.dP_flat = torch.empty((sum(sizes),), dtype=torch.bfloat16, device=dev)
+        self.dP, off = [], 0
+        for s, n in zip(p_shapes, sizes):
+            self.dP.append(self.dP_flat[off:off + n].view(s))
+            off += n
         self.dC = [None] + [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in c_shapes[1:]]
         self.planned = key
 

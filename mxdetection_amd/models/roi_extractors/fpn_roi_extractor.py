@@ -33,16 +33,33 @@ class FPNRoIExtractor:
         if shared_acc is not None:
             self.dacc = shared_acc
         if self.dacc is None:
-            self.dacc = [torch.empty(f.shape, dtype=torch.float32, device=self.device) for f in self.feats]
+            # one flat fp32 buffer, the levels are views: zero-fill and finalize are ONE launch each
+            sizes = [f.numel() for f in self.feats]
+            self.dacc_flat = torch.empty((sum(sizes),), dtype=torch.float32, device=self.device)
+            self.dacc, off = [], 0
+            for f, n in zip(self.feats, sizes):
+                self.dacc.append(self.dacc_flat[off:off + n].view(f.shape))
+                off += n
         if zero:
-            for a in self.dacc:
-                a.zero_()
+            if getattr(self, "dacc_flat", None) is not None:
+                self.dacc_flat.zero_()
+            else:
+                for a in self.dacc:
+                    a.zero_()
         roi_align_backward(self.dacc, self.scales, self.rois, self.levels, grad_out, self.sr, self.lvl_min)
         if finalize:
             self.finalize(dP)
         return self.dacc
 
     def finalize(self, dP, accumulate=False):
-        """dP[l] (+)= accumulators, rounded once to bf16."""
+        """dP[l] (+)= accumulators, rounded once to bf16 (one launch when both sides are views of flat buffers laid out
+        in the same order)."""
+        flat = getattr(self, "dacc_flat", None)
+        base = dP[0]._base if dP and dP[0]._base is not None else None
+        if (flat is not None and base is not None and base.dim() == 1 and base.numel() >= flat.numel() and
+                all(d._base is base for d in dP) and dP[0].storage_offset() == base.storage_offset() and
+                all(dP[i + 1].storage_offset() == dP[i].storage_offset() + dP[i].numel() for i in range(len(dP) - 1))):
+            dense.f32_accum_to_bf16(flat, base[:flat.numel()], accumulate=accumulate)
+            return
         for a, d in zip(self.dacc, dP):
             dense.f32_accum_to_bf16(a, d, accumulate=accumulate)
