@@ -82,6 +82,9 @@ SIGNATURES = {
                                     c_vp]),
     "mxdet_roi_align_bwd": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp,
                                     c_vp]),
+    "mxdet_roi_align_bwd_gather_workspace_bytes": (c_sz, [P(FeatPyramidT), c_i32, c_i64]),
+    "mxdet_roi_align_bwd_gather": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp,
+                                           c_i32, c_vp, c_sz, c_vp]),
     "mxdet_smooth_l1_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "mxdet_smooth_l1_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_i32, c_vp, c_vp]),
     "mxdet_loss_workspace_bytes": (c_sz, [c_i64]),

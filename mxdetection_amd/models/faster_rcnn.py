@@ -25,6 +25,10 @@ class FasterRCNN(DetectorBase):
         self.strides = [4, 8, 16, 32, 64]
         # registration order == backward completion order (buckets become final early)
         self.with_mask = with_mask
+        # False: fp32-atomic scatter form (310 us + zero-fill + finalize at the benchmark shape). True: deterministic
+        # gather form -- bit-reproducible, no fp32 accumulators, but as built its uniform per-(row, roi) control flow
+        # costs more than the atomics it saves (step 6.2 -> 7.1 ms): kept as the reproducible option, not the default.
+        self.roi_bwd_gather = False
         self.mask_head = None
         if with_mask:   # Mask R-CNN (BASELINE.json config 4): the mask branch's backward runs first
             self.mask_head = FCNMaskHead(256, self.arena, self.ws, device, gen, num_classes=num_classes,
@@ -109,11 +113,17 @@ class FasterRCNN(DetectorBase):
         if self.with_mask:
             d_mpooled = self.mask_head.backward()
         d_pooled = self.bbox_head.backward()
-        acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
-        if self.with_mask:
-            self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=False)
-        self._join_branch()
-        self.roi_extractor.finalize(self.dP[:4], accumulate=True)     # dP[l] = RPN part + RoI part
+        if self.roi_bwd_gather:
+            self._join_branch()                                       # dP[l] holds the RPN part
+            self.roi_extractor.backward_gather(d_pooled.view(pooled.shape), self.dP[:4], accumulate=True)
+            if self.with_mask:
+                self.mask_roi_extractor.backward_gather(d_mpooled, self.dP[:4], accumulate=True)
+        else:
+            acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
+            if self.with_mask:
+                self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=False)
+            self._join_branch()
+            self.roi_extractor.finalize(self.dP[:4], accumulate=True)     # dP[l] = RPN part + RoI part
         self._reduce(0, self.mark_rpn)
         self.neck.backward(self.dP, self.dC, [False, True, True, True])
         self._reduce(self.mark_rpn, self.mark_fpn)

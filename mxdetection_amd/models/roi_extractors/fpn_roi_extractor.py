@@ -5,7 +5,7 @@ Plugin slot: models/roi_extractors (/root/reference/README.md:32); MXNet role co
 import torch
 
 from ...ops import dense
-from ...ops.roi_align import fpn_level_map, roi_align_backward, roi_align_forward
+from ...ops.roi_align import fpn_level_map, roi_align_backward, roi_align_backward_gather, roi_align_forward
 
 
 class FPNRoIExtractor:
@@ -50,6 +50,12 @@ class FPNRoIExtractor:
         if finalize:
             self.finalize(dP)
         return self.dacc
+
+    def backward_gather(self, grad_out, dP, accumulate=True):
+        """Deterministic gather form: adds this extractor's gradient straight into the bf16 maps dP[l] (no fp32
+        accumulators, no atomics, no zero-fill / finalize passes)."""
+        roi_align_backward_gather(dP, self.scales, self.rois, self.levels, grad_out, self.sr, self.lvl_min,
+                                  accumulate=accumulate)
 
     def finalize(self, dP, accumulate=False):
         """dP[l] (+)= accumulators, rounded once to bf16 (one launch when both sides are views of flat buffers laid out

@@ -46,3 +46,25 @@ def roi_align_backward(dfeats, scales, rois, levels, grad_out, sampling_ratio=2,
     d = _pyr(dfeats, scales, lvl_min)
     check(lib.mxdet_roi_align_bwd(C.byref(d), N, C_, ptr(rois), ptr(levels), R, PH, PW, sampling_ratio,
                                   ptr(grad_out), stream_ptr()), "roi_align_bwd")
+
+
+_gather_ws = {}
+
+
+def roi_align_backward_gather(dmaps, scales, rois, levels, grad_out, sampling_ratio=2, lvl_min=2, accumulate=False,
+                              workspace=None):
+    """Deterministic gather form: writes (or adds to) the bf16 gradient maps dmaps[l] ([N,H,W,C]) directly."""
+    lib = _lib.load()
+    N, C_ = dmaps[0].shape[0], dmaps[0].shape[3]
+    R, PH, PW = grad_out.shape[0], grad_out.shape[1], grad_out.shape[2]
+    d = _pyr(dmaps, scales, lvl_min)
+    need = lib.mxdet_roi_align_bwd_gather_workspace_bytes(C.byref(d), N, R)
+    if workspace is None:
+        key = (dmaps[0].device, need)
+        workspace = _gather_ws.get(key)
+        if workspace is None:
+            workspace = torch.empty((max(need, 256),), dtype=torch.uint8, device=dmaps[0].device)
+            _gather_ws[key] = workspace
+    check(lib.mxdet_roi_align_bwd_gather(C.byref(d), N, C_, ptr(rois), ptr(levels), R, PH, PW, sampling_ratio,
+                                         ptr(grad_out), int(accumulate), ptr(workspace), workspace.numel(), stream_ptr()),
+          "roi_align_bwd_gather")

@@ -221,6 +221,42 @@ def test_roi_align_backward_tolerance(hip, oracle):
         assert np.allclose(g.cpu().numpy(), w, rtol=1e-5, atol=1e-5 * np.abs(w).max())
 
 
+def test_roi_align_backward_gather_form(hip, oracle):
+    """The deterministic gather form against the oracle (tolerance: its fixed summation order is not the oracle's) and
+    against itself (two runs bit-identical); written straight into bf16 maps, with and without accumulation."""
+    import torch
+    from mxdetection_amd.ops import roi_align_backward_gather
+    rng = np.random.default_rng(19)
+    N, C = 2, 40                       # C not a multiple of 64: lanes past C idle
+    shapes = [(50, 84), (25, 42), (13, 21)]
+    scales = [0.125, 0.0625, 0.03125]
+    feats = _feat_pyramid(rng, N, C, shapes, oracle)
+    R = 160
+    b = synth_boxes(rng, R, 400, 666)
+    b[:5] = [[0, 0, 0, 0], [660, 395, 665, 399], [-20, -20, 5, 5], [600, 300, 900, 700], [10, 10, 10.5, 10.5]]
+    rois = np.concatenate([rng.integers(0, N, (R, 1)).astype(np.float32), b], 1)
+    levels = rng.integers(3, 6, R).astype(np.int32)
+    go = oracle.f32_to_bf16_bits(rng.standard_normal((R, 7, 7, C)).astype(np.float32))
+    want = oracle.roi_align(feats, scales, rois, levels, 7, 7, 2, 3, grad_out_bits=go)
+    maps = [torch.full((N, H, W, C), 7.0, dtype=torch.bfloat16, device="cuda") for (H, W) in shapes]   # must be overwritten
+    roi_align_backward_gather(maps, scales, _t(rois), _t(levels), _bf16_t(go), 2, 3, accumulate=False)
+    first = [m.clone() for m in maps]
+    for g, w in zip(maps, want):
+        w16 = oracle.round_bf16(w)
+        # fp32 sums in a different fixed order, then one bf16 rounding: 1e-5 of the map's scale + half a bf16 ulp
+        assert np.allclose(g.float().cpu().numpy(), w16, rtol=2.0 ** -8, atol=1e-5 * np.abs(w).max())
+    roi_align_backward_gather(maps, scales, _t(rois), _t(levels), _bf16_t(go), 2, 3, accumulate=False)
+    for a, b2 in zip(first, maps):
+        assert torch.equal(a, b2)                                   # deterministic
+    base = [torch.from_numpy(oracle.round_bf16(rng.standard_normal((N, H, W, C)).astype(np.float32))).cuda().to(torch.bfloat16)
+            for (H, W) in shapes]
+    acc = [t.clone() for t in base]
+    roi_align_backward_gather(acc, scales, _t(rois), _t(levels), _bf16_t(go), 2, 3, accumulate=True)
+    for a, b0, w in zip(acc, base, want):
+        ref = b0.float().cpu().numpy() + w
+        assert np.allclose(a.float().cpu().numpy(), ref, rtol=2.0 ** -7, atol=2e-5 * np.abs(w).max() + 2.0 ** -8 * np.abs(ref).max())
+
+
 def test_rpn_loss_level(hip, oracle):
     import torch
     from mxdetection_amd.core import loss as L
