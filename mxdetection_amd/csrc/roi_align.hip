@@ -233,10 +233,11 @@ struct RoiRows {                       // row r of level l, image n has id row0[
   int tiles_w[8], block0[9];           // workgroups: block0[l] + (n * H[l] + y) * tiles_w[l] + tile
 };
 
-// one thread per pyramid row: the rois (ascending index) whose valid samples touch it
-__global__ void roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiTab* __restrict__ tab, int R,
-                                    unsigned short* __restrict__ row_list, int* __restrict__ row_count) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per pyramid row: the rois whose valid samples touch it, in ascending index order (ballot compaction)
+__global__ void __launch_bounds__(64)
+roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiTab* __restrict__ tab, int R,
+                    unsigned short* __restrict__ row_list, int* __restrict__ row_count) {
+  const int row = (int)blockIdx.x, lane = threadIdx.x;
   if (row >= rr.rows_total) return;
   int l = 0;
   while (l + 1 < f.num_levels && row >= rr.row0[l + 1]) ++l;
@@ -244,19 +245,30 @@ __global__ void roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiTab* __restr
   const int n = rel / f.H[l], y = rel - n * f.H[l];
   int cnt = 0;
   unsigned short* dst = row_list + (size_t)row * R;
-  for (int r = 0; r < R; ++r) {
-    const RoiTab& t = tab[r];
-    if (t.lvl == l && t.n == n && y >= t.ylo && y <= t.yhi && t.xlo <= t.xhi) dst[cnt++] = (unsigned short)r;
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int r = r0 + lane;
+    bool hit = false;
+    if (r < R) {
+      const RoiTab& t = tab[r];
+      hit = t.lvl == l && t.n == n && y >= t.ylo && y <= t.yhi && t.xlo <= t.xhi;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) dst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)r;
+    cnt += __popcll(m);
   }
-  row_count[row] = cnt;
+  if (lane == 0) row_count[row] = cnt;
 }
 
-__global__ void __launch_bounds__(256)
+// One WAVE per (pyramid row, 16-pixel segment); a lane owns 4 consecutive channels of each 256-channel chunk. All
+// control is lane-parallel or register-resident: the roi's sample tables sit one sample per lane, the samples that
+// hit this row / this segment come out of two ballots, and the loops walk the set bits with v_readlane -- no memory
+// latency inside them.
+__global__ void __launch_bounds__(64)
 roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restrict__ tab, int R,
                             const unsigned short* __restrict__ row_list, const int* __restrict__ row_count,
                             int PH, int PW, int sr, const uint16_t* __restrict__ gout, int accumulate) {
   int l = 0;
-  const int bid = (int)blockIdx.x;
+  const int bid = (int)blockIdx.x, lane = threadIdx.x;
   while (l + 1 < f.num_levels && bid >= rr.block0[l + 1]) ++l;
   const int rel = bid - rr.block0[l];
   const int tw = rr.tiles_w[l];
@@ -271,52 +283,74 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
   const int NSY = PH * sr, NSX = PW * sr;
   const float count = (float)(sr * sr);
   uint16_t* out = (uint16_t*)f.feat[l] + ((size_t)(n * H + Y) * W + x0) * C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc[kRoiTileW];
+  for (int cb = 0; cb < C; cb += 256) {          // uniform trip count: every lane takes part in the ballots below
+    const bool live = cb + lane * 4 < C;
+    const int c0 = live ? cb + lane * 4 : 0;
+    // four flat register arrays (one per channel of the lane), each indexed with a wave-uniform register index
+    float a0[kRoiTileW], a1[kRoiTileW], a2[kRoiTileW], a3[kRoiTileW];
 #pragma unroll
-    for (int j = 0; j < kRoiTileW; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < kRoiTileW; ++j) { a0[j] = 0.0f; a1[j] = 0.0f; a2[j] = 0.0f; a3[j] = 0.0f; }
     for (int k = 0; k < cnt; ++k) {
       const int r = list[k];
       const RoiTab& t = tab[r];
-      if (t.xhi < x0 || t.xlo > x1) continue;                 // uniform
-      const uint16_t* g0 = gout + (size_t)r * PH * PW * C + c;
-      for (int sy = 0; sy < NSY; ++sy) {
-        if (!t.vy[sy]) continue;
-        const int yl = t.yl[sy], yh = t.yh[sy];
-        if (yl != Y && yh != Y) continue;                      // uniform
+      // lane s holds row sample s and column sample s of this roi
+      const int ls = lane < kRoiMaxSamples ? lane : 0;
+      const int yl_ = t.yl[ls], yh_ = t.yh[ls], xl_ = t.xl[ls], xh_ = t.xh[ls];
+      const float hy_ = t.hy[ls], ly_ = t.ly[ls], hx_ = t.hx[ls], lx_ = t.lx[ls];
+      const bool vy_ = lane < NSY && t.vy[ls] != 0, vx_ = lane < NSX && t.vx[ls] != 0;
+      unsigned long long my = __ballot(vy_ && (yl_ == Y || yh_ == Y));
+      const unsigned long long mx = __ballot(vx_ && xh_ >= x0 && xl_ <= x1);
+      if (mx == 0ull) continue;
+      const uint16_t* g0 = gout + (size_t)r * PH * PW * C + c0;
+      while (my) {
+        const int sy = __ffsll((long long)my) - 1;
+        my &= my - 1;
+        const int yl = __builtin_amdgcn_readlane(yl_, sy), yh = __builtin_amdgcn_readlane(yh_, sy);
+        const float hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hy_), sy));
+        const float ly = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ly_), sy));
         const int ph = sy / sr;
-        for (int sx = 0; sx < NSX; ++sx) {
-          if (!t.vx[sx]) continue;
-          const int xl = t.xl[sx], xh = t.xh[sx];
-          if (xh < x0 || xl > x1) continue;                    // uniform
+        unsigned long long m2 = mx;
+        while (m2) {
+          const int sx = __ffsll((long long)m2) - 1;
+          m2 &= m2 - 1;
+          const int xl = __builtin_amdgcn_readlane(xl_, sx), xh = __builtin_amdgcn_readlane(xh_, sx);
+          const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hx_), sx));
+          const float lx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lx_), sx));
           const int pw = sx / sr;
-          const float go = bf16_bits_to_f32(g0[(size_t)(ph * PW + pw) * C]) / count;
-          if (go == 0.0f) continue;                            // as the scatter form: a zero gradient adds nothing
-          const float hx = t.hx[sx], lx = t.lx[sx];
-          // corner order of the scatter form: (yl,xl) (yl,xh) (yh,xl) (yh,xh). xl, xh are wave-uniform: the sums are
-          // indexed with a uniform register index (no per-pixel compare chain)
+          const uint2 gv = *(const uint2*)(g0 + (size_t)(ph * PW + pw) * C);
+          float go[4] = {__uint_as_float(gv.x << 16) / count, __uint_as_float(gv.x & 0xffff0000u) / count,
+                         __uint_as_float(gv.y << 16) / count, __uint_as_float(gv.y & 0xffff0000u) / count};
+          // corner order of the scatter form: (yl,xl) (yl,xh) (yh,xl) (yh,xh); a zero gradient adds nothing there and
+          // adds +0.0 here, which leaves every sum unchanged
           const int jl = xl - x0, jh = xh - x0;
           const bool inl = (unsigned)jl < (unsigned)kRoiTileW, inh = (unsigned)jh < (unsigned)kRoiTileW;
           if (yl == Y) {
-            const float hy = t.hy[sy];
-            if (inl) acc[jl] = acc[jl] + (hy * hx) * go;
-            if (inh) acc[jh] = acc[jh] + (hy * lx) * go;
+            const float wl = hy * hx, wh = hy * lx;
+            if (inl) { a0[jl] = a0[jl] + wl * go[0]; a1[jl] = a1[jl] + wl * go[1]; a2[jl] = a2[jl] + wl * go[2]; a3[jl] = a3[jl] + wl * go[3]; }
+            if (inh) { a0[jh] = a0[jh] + wh * go[0]; a1[jh] = a1[jh] + wh * go[1]; a2[jh] = a2[jh] + wh * go[2]; a3[jh] = a3[jh] + wh * go[3]; }
           }
           if (yh == Y) {
-            const float ly = t.ly[sy];
-            if (inl) acc[jl] = acc[jl] + (ly * hx) * go;
-            if (inh) acc[jh] = acc[jh] + (ly * lx) * go;
+            const float wl = ly * hx, wh = ly * lx;
+            if (inl) { a0[jl] = a0[jl] + wl * go[0]; a1[jl] = a1[jl] + wl * go[1]; a2[jl] = a2[jl] + wl * go[2]; a3[jl] = a3[jl] + wl * go[3]; }
+            if (inh) { a0[jh] = a0[jh] + wh * go[0]; a1[jh] = a1[jh] + wh * go[1]; a2[jh] = a2[jh] + wh * go[2]; a3[jh] = a3[jh] + wh * go[3]; }
           }
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < kRoiTileW; ++j) {
-      if (x0 + j >= W) break;
-      uint16_t* o = out + (size_t)j * C + c;
-      float v = acc[j];
-      if (accumulate) v = v + bf16_bits_to_f32(*o);
-      *o = f32_to_bf16_bits(v);
+      if (x0 + j >= W || !live) break;
+      uint16_t* o = out + (size_t)j * C + c0;
+      float v[4] = {a0[j], a1[j], a2[j], a3[j]};
+      if (accumulate) {
+        const uint2 e = *(const uint2*)o;
+        v[0] = v[0] + __uint_as_float(e.x << 16); v[1] = v[1] + __uint_as_float(e.x & 0xffff0000u);
+        v[2] = v[2] + __uint_as_float(e.y << 16); v[3] = v[3] + __uint_as_float(e.y & 0xffff0000u);
+      }
+      uint2 w;
+      w.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+      w.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+      *(uint2*)o = w;
     }
   }
 }
@@ -409,7 +443,7 @@ extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t
   FeatPyr d;
   int rc = fill(d, f, N, "roi_align_bwd_gather");
   if (rc) return rc;
-  MXDET_REQUIRE(N > 0 && C > 0 && PH > 0 && PW > 0 && R >= 0, MXDET_ESHAPE, "roi_align_bwd_gather: bad shape");
+  MXDET_REQUIRE(N > 0 && C > 0 && (C % 4) == 0 && PH > 0 && PW > 0 && R >= 0, MXDET_ESHAPE, "roi_align_bwd_gather: bad shape (C must be a multiple of 4)");
   MXDET_REQUIRE(sampling_ratio > 0 && PH * sampling_ratio <= kRoiMaxSamples && PW * sampling_ratio <= kRoiMaxSamples,
                 MXDET_ESHAPE, "roi_align_bwd_gather: needs 0 < sampling_ratio and at most %d samples per axis", kRoiMaxSamples);
   MXDET_REQUIRE(R <= 65535, MXDET_ESHAPE, "roi_align_bwd_gather: at most 65535 rois");
@@ -427,9 +461,9 @@ extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t
   if (R > 0)
     hipLaunchKernelGGL(roi_bwd_tab_kernel, dim3((unsigned)ceil_div<long long>(R, 64)), dim3(64), 0, s, d, rois, levels,
                        (long long)R, PH, PW, sampling_ratio, tab);
-  hipLaunchKernelGGL(roi_bwd_rows_kernel, dim3(ceil_div(rr.rows_total, 64)), dim3(64), 0, s, d, rr, (const RoiTab*)tab,
+  hipLaunchKernelGGL(roi_bwd_rows_kernel, dim3(rr.rows_total), dim3(64), 0, s, d, rr, (const RoiTab*)tab,
                      (int)R, list, cnt);
-  hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)rr.block0[d.num_levels]), dim3(256), 0, s, d, rr, C,
+  hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)rr.block0[d.num_levels]), dim3(64), 0, s, d, rr, C,
                      (const RoiTab*)tab, (int)R, (const unsigned short*)list, (const int*)cnt, PH, PW, sampling_ratio,
                      grad_out, accumulate);
   return check_launch("roi_align_bwd_gather");

@@ -25,10 +25,9 @@ class FasterRCNN(DetectorBase):
         self.strides = [4, 8, 16, 32, 64]
         # registration order == backward completion order (buckets become final early)
         self.with_mask = with_mask
-        # False: fp32-atomic scatter form (310 us + zero-fill + finalize at the benchmark shape). True: deterministic
-        # gather form -- bit-reproducible, no fp32 accumulators, but as built its uniform per-(row, roi) control flow
-        # costs more than the atomics it saves (step 6.2 -> 7.1 ms): kept as the reproducible option, not the default.
-        self.roi_bwd_gather = False
+        # RoIAlign backward: deterministic gather form (no atomics, no fp32 accumulators, writes the bf16 maps directly);
+        # False selects the fp32-atomic scatter form (310 us + zero-fill + finalize at the benchmark shape)
+        self.roi_bwd_gather = True
         self.mask_head = None
         if with_mask:   # Mask R-CNN (BASELINE.json config 4): the mask branch's backward runs first
             self.mask_head = FCNMaskHead(256, self.arena, self.ws, device, gen, num_classes=num_classes,
