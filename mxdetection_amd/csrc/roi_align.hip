@@ -282,6 +282,8 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
   const unsigned short* list = row_list + (size_t)row * R;
   const int NSY = PH * sr, NSX = PW * sr;
   const float count = (float)(sr * sr);
+  const bool pow2 = ((sr * sr) & (sr * sr - 1)) == 0;
+  const float inv_count = 1.0f / count;
   uint16_t* out = (uint16_t*)f.feat[l] + ((size_t)(n * H + Y) * W + x0) * C;
   for (int cb = 0; cb < C; cb += 256) {          // uniform trip count: every lane takes part in the ballots below
     const bool live = cb + lane * 4 < C;
@@ -290,8 +292,18 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
     float a0[kRoiTileW], a1[kRoiTileW], a2[kRoiTileW], a3[kRoiTileW];
 #pragma unroll
     for (int j = 0; j < kRoiTileW; ++j) { a0[j] = 0.0f; a1[j] = 0.0f; a2[j] = 0.0f; a3[j] = 0.0f; }
-    for (int k = 0; k < cnt; ++k) {
-      const int r = list[k];
+    bool touched = false;                          // wave-uniform: did any roi reach this segment?
+    for (int base = 0; base < cnt; base += 64) {
+     // 64 rois of the row at a time: lane k tests roi base+k against this 16-pixel segment; only the hits (one in ten
+     // on the finest level) get their tables loaded
+     const int kk = base + lane;
+     const int rk = kk < cnt ? list[kk] : 0;
+     const bool hitk = kk < cnt && tab[rk].xhi >= x0 && tab[rk].xlo <= x1;
+     unsigned long long mr = __ballot(hitk);
+     while (mr) {
+      const int kb = __ffsll((long long)mr) - 1;
+      mr &= mr - 1;
+      const int r = __builtin_amdgcn_readlane(rk, kb);
       const RoiTab& t = tab[r];
       // lane s holds row sample s and column sample s of this roi
       const int ls = lane < kRoiMaxSamples ? lane : 0;
@@ -300,7 +312,8 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
       const bool vy_ = lane < NSY && t.vy[ls] != 0, vx_ = lane < NSX && t.vx[ls] != 0;
       unsigned long long my = __ballot(vy_ && (yl_ == Y || yh_ == Y));
       const unsigned long long mx = __ballot(vx_ && xh_ >= x0 && xl_ <= x1);
-      if (mx == 0ull) continue;
+      if (mx == 0ull || my == 0ull) continue;
+      touched = true;
       const uint16_t* g0 = gout + (size_t)r * PH * PW * C + c0;
       while (my) {
         const int sy = __ffsll((long long)my) - 1;
@@ -310,33 +323,49 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
         const float ly = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ly_), sy));
         const int ph = sy / sr;
         unsigned long long m2 = mx;
+        // two column samples per trip: their gradient loads are independent and overlap (the loop is otherwise one
+        // L2 round trip per sample)
         while (m2) {
-          const int sx = __ffsll((long long)m2) - 1;
+          const int sxa = __ffsll((long long)m2) - 1;
           m2 &= m2 - 1;
-          const int xl = __builtin_amdgcn_readlane(xl_, sx), xh = __builtin_amdgcn_readlane(xh_, sx);
-          const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hx_), sx));
-          const float lx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lx_), sx));
-          const int pw = sx / sr;
-          const uint2 gv = *(const uint2*)(g0 + (size_t)(ph * PW + pw) * C);
-          float go[4] = {__uint_as_float(gv.x << 16) / count, __uint_as_float(gv.x & 0xffff0000u) / count,
-                         __uint_as_float(gv.y << 16) / count, __uint_as_float(gv.y & 0xffff0000u) / count};
-          // corner order of the scatter form: (yl,xl) (yl,xh) (yh,xl) (yh,xh); a zero gradient adds nothing there and
-          // adds +0.0 here, which leaves every sum unchanged
-          const int jl = xl - x0, jh = xh - x0;
-          const bool inl = (unsigned)jl < (unsigned)kRoiTileW, inh = (unsigned)jh < (unsigned)kRoiTileW;
-          if (yl == Y) {
-            const float wl = hy * hx, wh = hy * lx;
-            if (inl) { a0[jl] = a0[jl] + wl * go[0]; a1[jl] = a1[jl] + wl * go[1]; a2[jl] = a2[jl] + wl * go[2]; a3[jl] = a3[jl] + wl * go[3]; }
-            if (inh) { a0[jh] = a0[jh] + wh * go[0]; a1[jh] = a1[jh] + wh * go[1]; a2[jh] = a2[jh] + wh * go[2]; a3[jh] = a3[jh] + wh * go[3]; }
-          }
-          if (yh == Y) {
-            const float wl = ly * hx, wh = ly * lx;
-            if (inl) { a0[jl] = a0[jl] + wl * go[0]; a1[jl] = a1[jl] + wl * go[1]; a2[jl] = a2[jl] + wl * go[2]; a3[jl] = a3[jl] + wl * go[3]; }
-            if (inh) { a0[jh] = a0[jh] + wh * go[0]; a1[jh] = a1[jh] + wh * go[1]; a2[jh] = a2[jh] + wh * go[2]; a3[jh] = a3[jh] + wh * go[3]; }
+          const bool two = m2 != 0ull;
+          const int sxb = two ? __ffsll((long long)m2) - 1 : sxa;
+          if (two) m2 &= m2 - 1;
+          const uint2 gva = *(const uint2*)(g0 + (size_t)(ph * PW + sxa / sr) * C);
+          const uint2 gvb = *(const uint2*)(g0 + (size_t)(ph * PW + sxb / sr) * C);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !two) break;
+            const int sx = half ? sxb : sxa;
+            const uint2 gv = half ? gvb : gva;
+            const int xl = __builtin_amdgcn_readlane(xl_, sx), xh = __builtin_amdgcn_readlane(xh_, sx);
+            const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hx_), sx));
+            const float lx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lx_), sx));
+            float go[4] = {__uint_as_float(gv.x << 16), __uint_as_float(gv.x & 0xffff0000u),
+                           __uint_as_float(gv.y << 16), __uint_as_float(gv.y & 0xffff0000u)};
+            // grad / count: a power-of-two count (sampling_ratio 1, 2, 4) divides exactly as a multiplication
+            if (pow2) { go[0] *= inv_count; go[1] *= inv_count; go[2] *= inv_count; go[3] *= inv_count; }
+            else { go[0] /= count; go[1] /= count; go[2] /= count; go[3] /= count; }
+            // corner order of the scatter form: (yl,xl) (yl,xh) (yh,xl) (yh,xh); a zero gradient adds nothing there
+            // and adds +0.0 here, which leaves every sum unchanged
+            const int jl = xl - x0, jh = xh - x0;
+            const bool inl = (unsigned)jl < (unsigned)kRoiTileW, inh = (unsigned)jh < (unsigned)kRoiTileW;
+            if (yl == Y) {
+              const float wl = hy * hx, wh = hy * lx;
+              if (inl) { a0[jl] = a0[jl] + wl * go[0]; a1[jl] = a1[jl] + wl * go[1]; a2[jl] = a2[jl] + wl * go[2]; a3[jl] = a3[jl] + wl * go[3]; }
+              if (inh) { a0[jh] = a0[jh] + wh * go[0]; a1[jh] = a1[jh] + wh * go[1]; a2[jh] = a2[jh] + wh * go[2]; a3[jh] = a3[jh] + wh * go[3]; }
+            }
+            if (yh == Y) {
+              const float wl = ly * hx, wh = ly * lx;
+              if (inl) { a0[jl] = a0[jl] + wl * go[0]; a1[jl] = a1[jl] + wl * go[1]; a2[jl] = a2[jl] + wl * go[2]; a3[jl] = a3[jl] + wl * go[3]; }
+              if (inh) { a0[jh] = a0[jh] + wh * go[0]; a1[jh] = a1[jh] + wh * go[1]; a2[jh] = a2[jh] + wh * go[2]; a3[jh] = a3[jh] + wh * go[3]; }
+            }
           }
         }
       }
+     }
     }
+    if (accumulate && !touched) continue;          // nothing to add: leave the map as it is (no read-modify-write)
 #pragma unroll
     for (int j = 0; j < kRoiTileW; ++j) {
       if (x0 + j >= W || !live) break;
