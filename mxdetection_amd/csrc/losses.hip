@@ -371,6 +371,105 @@ __global__ void anchor_class_labels_kernel(const int32_t* __restrict__ labels, c
 }
 
 // one thread per (cell, anchor): C contiguous class logits at cls[cell*ld_cls + a*C], 4 deltas at reg[cell*ld_reg + a*4]
+// Vectorised form (C % 8 == 0): a workgroup still owns 256 consecutive anchors (so the partial-sum layout is unchanged),
+// but the class logits are walked 16 bytes per lane with consecutive lanes on consecutive addresses -- the scalar form
+// below has every lane striding C*2 bytes apart with 2-byte accesses (920 us per step on RetinaNet-R101 for 129 MB).
+__global__ void __launch_bounds__(256)
+retina_loss_vec_kernel(const uint16_t* __restrict__ cls, const uint16_t* __restrict__ reg, int N, int HW, int A, int C,
+                       int ld_cls, int ld_reg, const int32_t* __restrict__ cls_labels,
+                       const float4* __restrict__ targets, long long A_total, long long level_offset, float alpha,
+                       float gamma, float sigma2, const int* __restrict__ num_fg, float loss_scale,
+                       uint16_t* __restrict__ gcls, uint16_t* __restrict__ greg, float* __restrict__ partial) {
+  __shared__ float red[8];
+  const long long total = (long long)N * HW * A;
+  const long long a_first = (long long)blockIdx.x * 256;
+  const int nf = *num_fg;
+  const float inv = 1.0f / (float)(nf > 1 ? nf : 1);
+  const int CH = C >> 3;
+  float lc = 0.0f, lr = 0.0f;
+  for (int it = threadIdx.x; it < 256 * CH; it += 256) {
+    const int al = it / CH, ck = it - al * CH;
+    const long long idx = a_first + al;
+    if (idx >= total) continue;
+    const int a = (int)(idx % A);
+    const long long cell = idx / A;
+    const int n = (int)(cell / HW);
+    const long long local = cell - (long long)n * HW;
+    const int lab = cls_labels[(long long)n * A_total + level_offset + local * A + a];
+    const long long off = cell * ld_cls + (long long)a * C + ck * 8;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (lab >= 0) {
+      const uint4 zv = *(const uint4*)(cls + off);
+      const unsigned zw[4] = {zv.x, zv.y, zv.z, zv.w};
+      unsigned ow[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned packed = 0u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = ck * 8 + 2 * k + h;
+          const float x = h ? __uint_as_float(zw[k] & 0xffff0000u) : __uint_as_float(zw[k] << 16);
+          const float p = sigmoidf_det(x);
+          const float sp = softplus_neg_abs(x);
+          const float logp = -((x < 0.0f ? -x : 0.0f) + sp);
+          const float log1mp = -((x > 0.0f ? x : 0.0f) + sp);
+          float g;
+          if (lab == c + 1) {
+            const float q = 1.0f - p;
+            const float mod = (gamma == 2.0f) ? q * q : mxdet_expf(gamma * mxdet_logf(q > 1e-30f ? q : 1e-30f));
+            lc += -alpha * mod * logp;
+            g = -alpha * mod * (q - gamma * p * logp);
+          } else {
+            const float mod = (gamma == 2.0f) ? p * p : mxdet_expf(gamma * mxdet_logf(p > 1e-30f ? p : 1e-30f));
+            lc += -(1.0f - alpha) * mod * log1mp;
+            g = (1.0f - alpha) * mod * (p - gamma * (1.0f - p) * log1mp);
+          }
+          packed |= (unsigned)f32_to_bf16_bits(g * inv * loss_scale) << (16 * h);
+        }
+        ow[k] = packed;
+      }
+      o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+    *(uint4*)(gcls + off) = o;
+  }
+  {   // box part: one lane per anchor, 8 bytes in, 8 bytes out
+    const long long idx = a_first + threadIdx.x;
+    if (idx < total) {
+      const int a = (int)(idx % A);
+      const long long cell = idx / A;
+      const int n = (int)(cell / HW);
+      const long long local = cell - (long long)n * HW;
+      const long long gi = (long long)n * A_total + level_offset + local * A + a;
+      const int lab = cls_labels[gi];
+      const uint16_t* d = reg + cell * ld_reg + a * 4;
+      uint16_t* gd = greg + cell * ld_reg + a * 4;
+      uint2 go = make_uint2(0u, 0u);
+      if (lab > 0) {
+        const float4 t = targets[gi];
+        const uint2 dv = *(const uint2*)d;
+        const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u),
+                             __uint_as_float(dv.y << 16), __uint_as_float(dv.y & 0xffff0000u)};
+        const float tt[4] = {t.x, t.y, t.z, t.w};
+        unsigned short gb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float e = dd[k] - tt[k];
+          lr += mxdet_smooth_l1(e, sigma2);
+          gb[k] = f32_to_bf16_bits(mxdet_smooth_l1_grad(e, sigma2) * inv * loss_scale);
+        }
+        go = make_uint2((unsigned)gb[0] | ((unsigned)gb[1] << 16), (unsigned)gb[2] | ((unsigned)gb[3] << 16));
+      }
+      *(uint2*)gd = go;
+    }
+  }
+  float s0 = block_sum_fixed(lc, red);
+  float s1 = block_sum_fixed(lr, red);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x + 0] = s0 * inv;
+    partial[2 * blockIdx.x + 1] = s1 * inv;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 retina_loss_kernel(const uint16_t* __restrict__ cls, const uint16_t* __restrict__ reg, int N, int HW, int A, int C,
                    int ld_cls, int ld_reg, const int32_t* __restrict__ cls_labels, const float4* __restrict__ targets,
@@ -472,8 +571,16 @@ extern "C" int mxdet_retina_loss_level(const uint16_t* cls, const uint16_t* reg,
   MXDET_REQUIRE(level_offset >= 0 && level_offset + (int64_t)H * W * A <= A_total, MXDET_ESHAPE,
                 "retina_loss_level: level outside the anchor range");
   int blocks = mxdet_retina_loss_num_partials(N, H, W, A);
-  hipLaunchKernelGGL(retina_loss_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), cls, reg, N, H * W, A, C, ld_cls,
-                     ld_reg, cls_labels, (const float4*)bbox_targets, (long long)A_total, (long long)level_offset, alpha,
-                     gamma, sigma * sigma, (const int*)num_fg, loss_scale, grad_cls, grad_reg, partial);
+  // 16-byte path: whole 8-channel chunks per anchor and 16-B / 8-B aligned rows
+  const bool vec = (C % 8 == 0) && (ld_cls % 8 == 0) && (ld_reg % 4 == 0) && (((uintptr_t)cls | (uintptr_t)grad_cls) % 16 == 0) &&
+                   (((uintptr_t)reg | (uintptr_t)grad_reg) % 8 == 0);
+  if (vec)
+    hipLaunchKernelGGL(retina_loss_vec_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), cls, reg, N, H * W, A, C,
+                       ld_cls, ld_reg, cls_labels, (const float4*)bbox_targets, (long long)A_total, (long long)level_offset,
+                       alpha, gamma, sigma * sigma, (const int*)num_fg, loss_scale, grad_cls, grad_reg, partial);
+  else
+    hipLaunchKernelGGL(retina_loss_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), cls, reg, N, H * W, A, C, ld_cls,
+                       ld_reg, cls_labels, (const float4*)bbox_targets, (long long)A_total, (long long)level_offset, alpha,
+                       gamma, sigma * sigma, (const int*)num_fg, loss_scale, grad_cls, grad_reg, partial);
   return check_launch("retina_loss_level");
 }
