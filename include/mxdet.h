@@ -381,6 +381,44 @@ int mxdet_subsample2_bwd(const uint16_t* dy, int32_t N, int32_t H, int32_t W, in
 /* adjoint of the nearest-neighbour 2x upsample: dcoarse[N,Hc,Wc,C] (+)= sum of the 2x2 fine cells */
 int mxdet_upsample2_bwd(const uint16_t* dfine, int32_t N, int32_t Hf, int32_t Wf, int32_t C,
                         int32_t accumulate, uint16_t* dcoarse, mxdet_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * process_data (README.md:23) -- the step in front of the path.
+ * MXNet-lineage role: the host-side cv2 pipeline  flip -> cv2.resize(fx=fy=scale, INTER_LINEAR) -> BGR->RGB,
+ * minus pixel mean (over std) -> NCHW -> zero-pad the batch to a common size. Here one launch turns the decoded
+ * 8-bit frames of a batch into the bf16 NCHW tensor the stem kernel reads.
+ *
+ * Resize arithmetic = OpenCV's 8-bit bilinear (the reference names cv2 as its resizer, README.md:53-56, no version
+ * pinned; restated from its published imgproc/resize.cpp, parity with a cv2 build is UNPINNED -- cv2 is not in the
+ * image): with inv = 1/scale in double,
+ *   fx = (float)((dx + 0.5) * inv - 0.5); sx = floor(fx); fx -= sx; sx < 0 -> (0, 0); sx >= sw-1 -> (sw-1, 0)
+ *   a1 = rint(fx * 2048), a0 = rint((1 - fx) * 2048)           (11-bit coefficients, round half even)
+ *   row(y) = S[y][sx] * a0 + S[y][min(sx+1, sw-1)] * a1;         same for dy -> (sy, b0, b1)
+ *   v = (((b0 * (row(sy) >> 4)) >> 16) + ((b1 * (row(sy+1) >> 4)) >> 16) + 2) >> 2
+ * then out = (v - mean[c]) / std[c] in fp32 (IEEE, unfused), rounded to bf16 (nearest even).
+ * flip mirrors the SOURCE columns (flip-then-resize, the order the lineage uses); swap_rb reads source channel 2-c.
+ * Pixels outside (dst_h, dst_w) of their image are written as zero: out is [N, 3, Hp, Wp], Wp % 8 == 0. */
+typedef struct {
+  const uint8_t* src;     /* device pointer, [src_h, src_w, 3] 8-bit interleaved, row pitch src_w*3 */
+  int32_t src_h, src_w;
+  int32_t dst_h, dst_w;   /* rint(src * scale), <= Hp / Wp */
+  int32_t flip;           /* mirror columns */
+  int32_t pad_;
+  double inv_scale;       /* 1 / scale */
+} mxdet_image_desc_t;
+#define MXDET_PREPROCESS_MAX_BATCH 64
+int mxdet_image_preprocess(const mxdet_image_desc_t* images /* host array */, int32_t N, int32_t Hp, int32_t Wp,
+                           const float* mean3 /* host */, const float* std3 /* host */, int32_t swap_rb,
+                           uint16_t* out, mxdet_stream_t stream);
+
+/* Instance masks from polygons (datasets: COCO "segmentation" lists), written straight at network resolution.
+ * verts [V,2] f32 (x,y) already scaled/flipped into the resized image; poly_start [P+1] i32 offsets into verts
+ * (polygons of one instance adjacent, instances in n*G+g order); inst_first [N*G+1] i32 offsets into the polygon list. masks [N,G,H,W] u8: 1 where the pixel centre (x+0.5, y+0.5) is inside an odd number of edges
+ * of ANY polygon of the instance (union of even-odd fills), else 0; instances without polygons are all zero.
+ * Edge rule: (y0 <= py) != (y1 <= py) and px < x0 + (py - y0) * (x1 - x0) / (y1 - y0), fp32 unfused.
+ * pycocotools' frPoly walks a 5x upsampled boundary instead; the two differ only on boundary pixels (unpinned). */
+int mxdet_polygon_masks(const float* verts, const int32_t* poly_start, const int32_t* inst_first, int32_t N,
+                        int32_t G, int32_t H, int32_t W, uint8_t* masks, mxdet_stream_t stream);
+
 /* elementwise helpers on channels-last tensors */
 int mxdet_add_bf16(const uint16_t* a, const uint16_t* b, int64_t n, uint16_t* out,
                    mxdet_stream_t stream);

@@ -32,6 +32,12 @@ class FeatPyramidT(C.Structure):
     ]
 
 
+class ImageDescT(C.Structure):
+    """mxdet_image_desc_t (include/mxdet.h)."""
+    _fields_ = [("src", C.c_void_p), ("src_h", C.c_int32), ("src_w", C.c_int32), ("dst_h", C.c_int32),
+                ("dst_w", C.c_int32), ("flip", C.c_int32), ("pad_", C.c_int32), ("inv_scale", C.c_double)]
+
+
 class WgradItemT(C.Structure):
     pass
 
@@ -65,6 +71,8 @@ SIGNATURES = {
     "mxdet_generate_anchors": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_nms_batched_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "mxdet_nms_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_image_preprocess": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "mxdet_polygon_masks": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_detection_postprocess_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "mxdet_detection_postprocess": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                             P(c_f32), P(c_f32), c_f32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -865,3 +865,74 @@ API void oracle_detection_postprocess(const float* cls, const float* reg, const 
   }
   free(cand); free(kept); free(bx); free(keep); free(sc); free(bb);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * process_data (README.md:23): flip -> 8-bit bilinear resize -> channel swap, (v - mean) / std -> bf16 NCHW, zero pad.
+ * The resize restates OpenCV's 8-bit INTER_LINEAR path (imgproc/resize.cpp: resizeGeneric_ coefficient set-up with
+ * INTER_RESIZE_COEF_BITS = 11, HResizeLinear, VResizeLinear's FixedPtCast<int, uchar, 22>); cv2 is the resizer the
+ * reference names (README.md:53-56). Parity with a cv2 build is UNPINNED: cv2 is not in this image. */
+static void o_resize_coef(int d, double inv, int slen, int* s0, int* s1, int* c0, int* c1) {
+  float f = (float)(((double)d + 0.5) * inv - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.0f; s = 0; }
+  if (s >= slen - 1) { f = 0.0f; s = slen - 1; }
+  *s0 = s;
+  *s1 = s + 1 < slen ? s + 1 : slen - 1;
+  *c0 = (int)lrintf((1.0f - f) * 2048.0f);
+  *c1 = (int)lrintf(f * 2048.0f);
+}
+/* one image: src [sh][sw][3] u8 -> out planes [3][Hp][Wp] bf16 bits (out points at image n's first plane).
+ * resized_u8, if not NULL, receives the [dh][dw][3] 8-bit resize result (before normalisation, after flip + swap). */
+API void oracle_image_preprocess(const uint8_t* src, int sh, int sw, int dh, int dw, int flip, double inv_scale,
+                                 int Hp, int Wp, const float* mean3, const float* std3, int swap_rb, uint16_t* out,
+                                 uint8_t* resized_u8) {
+  for (size_t i = 0; i < (size_t)3 * Hp * Wp; ++i) out[i] = 0;
+  for (int y = 0; y < dh; ++y) {
+    int sy0, sy1, b0, b1;
+    o_resize_coef(y, inv_scale, sh, &sy0, &sy1, &b0, &b1);
+    for (int x = 0; x < dw; ++x) {
+      int sx0, sx1, a0, a1;
+      o_resize_coef(x, inv_scale, sw, &sx0, &sx1, &a0, &a1);
+      if (flip) { sx0 = sw - 1 - sx0; sx1 = sw - 1 - sx1; }
+      for (int c = 0; c < 3; ++c) {
+        const int sc = swap_rb ? 2 - c : c;
+        const int t0 = (int)src[((size_t)sy0 * sw + sx0) * 3 + sc] * a0 + (int)src[((size_t)sy0 * sw + sx1) * 3 + sc] * a1;
+        const int t1 = (int)src[((size_t)sy1 * sw + sx0) * 3 + sc] * a0 + (int)src[((size_t)sy1 * sw + sx1) * 3 + sc] * a1;
+        const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        if (resized_u8) resized_u8[((size_t)y * dw + x) * 3 + c] = (uint8_t)v;
+        const float f = ((float)v - mean3[c]) / std3[c];
+        out[((size_t)c * Hp + y) * Wp + x] = mxdet_f32_to_bf16(f);
+      }
+    }
+  }
+}
+
+/* datasets: polygon lists -> instance masks [NG][H][W] u8; pixel-centre even-odd fill per polygon, union per instance */
+API void oracle_polygon_masks(const float* verts, const int32_t* poly_start, const int32_t* inst_first, int NG, int H,
+                              int W, uint8_t* masks) {
+  for (int inst = 0; inst < NG; ++inst)
+    for (int y = 0; y < H; ++y) {
+      const float py = (float)y + 0.5f;
+      for (int x = 0; x < W; ++x) {
+        const float px = (float)x + 0.5f;
+        int inside = 0;
+        for (int p = inst_first[inst]; p < inst_first[inst + 1]; ++p) {
+          const int vb = poly_start[p], ve = poly_start[p + 1];
+          if (ve - vb < 3) continue;
+          int par = 0;
+          float ax = verts[2 * (ve - 1)], ay = verts[2 * (ve - 1) + 1];
+          for (int v = vb; v < ve; ++v) {
+            const float bx = verts[2 * v], by = verts[2 * v + 1];
+            if ((ay <= py) != (by <= py)) {
+              const float xi = ax + ((py - ay) * (bx - ax)) / (by - ay);
+              if (px < xi) par ^= 1;
+            }
+            ax = bx; ay = by;
+          }
+          inside |= par;
+        }
+        masks[((size_t)inst * H + y) * W + x] = (uint8_t)inside;
+      }
+    }
+}

@@ -358,3 +358,28 @@ def detection_postprocess(cls, reg, rois, num_rois, im_info, means, stds, score_
                                        C.c_float(score_thresh), C.c_float(nms_thresh), C.c_int(max_det), _vp(dets), _vp(num),
                                        _vp(sc), _vp(bb))
     return dets, num, sc, bb
+
+
+def image_preprocess(images, scales, flips, Hp, Wp, mean, std, swap_rb=True, return_u8=False):
+    """images: list of u8 [h,w,3]; scales: list of float (python double). Returns bf16 bits [N,3,Hp,Wp] (+ the 8-bit
+    resize results). dst size = rint(src * scale) (round half even, = cv2's saturate_cast<int>)."""
+    N = len(images)
+    out = np.zeros((N, 3, Hp, Wp), np.uint16)
+    u8 = []
+    for n, im in enumerate(images):
+        im = _c(im, np.uint8)
+        sh, sw = im.shape[:2]
+        dh, dw = int(round(sh * scales[n])), int(round(sw * scales[n]))
+        r8 = np.zeros((dh, dw, 3), np.uint8)
+        lib().oracle_image_preprocess(_vp(im), C.c_int(sh), C.c_int(sw), C.c_int(dh), C.c_int(dw), C.c_int(int(flips[n])),
+                                      C.c_double(1.0 / scales[n]), C.c_int(Hp), C.c_int(Wp), _vp(_c(mean, np.float32)),
+                                      _vp(_c(std, np.float32)), C.c_int(int(swap_rb)), _vp(out[n]), _vp(r8))
+        u8.append(r8)
+    return (out, u8) if return_u8 else out
+
+
+def polygon_masks(verts, poly_start, inst_first, NG, H, W):
+    verts, poly_start, inst_first = _c(verts, np.float32), _c(poly_start, np.int32), _c(inst_first, np.int32)
+    masks = np.zeros((NG, H, W), np.uint8)
+    lib().oracle_polygon_masks(_vp(verts), _vp(poly_start), _vp(inst_first), C.c_int(NG), C.c_int(H), C.c_int(W), _vp(masks))
+    return masks

@@ -64,6 +64,21 @@ def main():
     dets, num, _, _ = O.detection_postprocess(pp_cls, pp_reg, pp_rois, [40, 33], info, (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2),
                                               0.05, 0.5, 20)
     d.update(pp_rois=pp_rois, pp_cls=pp_cls, pp_reg=pp_reg, pp_dets=dets, pp_num=num)
+    # data pipeline (process_data / datasets): two small frames, one flipped, fractional scales; polygons incl. a
+    # concave one, a two-polygon instance and an empty instance. Own generator: the arrays above stay untouched.
+    r2 = np.random.default_rng(77)
+    im0 = r2.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    im1 = r2.integers(0, 256, (19, 11, 3), dtype=np.uint8)
+    dp_scales = np.array([1.37, 2.0 / 3.0], np.float64)
+    dp_out, dp_u8 = O.image_preprocess([im0, im1], dp_scales.tolist(), [False, True], 32, 32, (123.68, 116.779, 103.939),
+                                       (58.4, 57.1, 57.4), swap_rb=True, return_u8=True)
+    polys = [[[2.0, 1.5, 20.5, 3.0, 18.0, 14.2, 9.0, 6.0, 3.5, 15.0]],                  # concave
+             [[1.0, 1.0, 6.0, 1.0, 6.0, 6.0, 1.0, 6.0], [4.0, 4.0, 12.0, 5.0, 8.0, 11.0]],   # union of two
+             []]
+    from mxdetection_amd.process_data.transform import pack_polygons
+    pv, ps, pf = pack_polygons([[[np.asarray(q, np.float32).reshape(-1, 2) for q in inst] for inst in polys]], 1, 3)
+    d.update(dp_im0=im0, dp_im1=im1, dp_scales=dp_scales, dp_out=dp_out, dp_u8_0=dp_u8[0], dp_u8_1=dp_u8[1],
+             pm_verts=pv, pm_start=ps, pm_first=pf, pm_masks=O.polygon_masks(pv, ps, pf, 3, 16, 24))
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "det_small.npz"), **d)
     print("wrote det_small.npz with", len(d), "arrays")
 
