@@ -444,6 +444,11 @@ int mxdet_nhwc_to_nchw_f32(const uint16_t* x, int32_t N, int32_t C, int32_t H, i
 int mxdet_sgd_momentum_update(float* w, const float* grad, float* mom, uint16_t* w_bf16, int64_t n,
                               float lr, float momentum, float wd, float rescale,
                               mxdet_stream_t stream);
+/* Same update with the learning rate read from device memory (lr_dev[0]) when the kernel runs: a step captured into
+ * a hipGraph follows the warm-up / step schedule (MXNet role: lr_scheduler feeding the optimizer) without re-capture. */
+int mxdet_sgd_momentum_update_sched(float* w, const float* grad, float* mom, uint16_t* w_bf16, int64_t n,
+                                    const float* lr_dev, float momentum, float wd, float rescale,
+                                    mxdet_stream_t stream);
 
 #ifdef __cplusplus
 }

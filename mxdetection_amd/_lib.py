@@ -138,6 +138,7 @@ SIGNATURES = {
     "mxdet_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_sgd_momentum_update": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "mxdet_sgd_momentum_update_sched": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_f32, c_f32, c_vp]),
 }
 
 _lib = None

@@ -47,3 +47,207 @@ class DetectionPostprocess:
                                               self.nms_thresh, self.max_det, ptr(dets), ptr(num), ptr(self._ws),
                                               self._ws.numel(), stream_ptr()), "detection_postprocess")
         return dets, num
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Offline accuracy metrics (README.md:20 `core/evaluation`: COCO / VOC mAP). Host-side numpy: they run once per epoch
+# on a few thousand boxes, far from the img/s path. Restated from the published COCO evaluation protocol
+# (pycocotools.cocoeval: per-image greedy matching in score order at IoU 0.50:0.05:0.95, crowd / out-of-range ground
+# truth ignored, 101-point interpolated precision) and the VOC devkit's AP; neither package is in this image, so the
+# numbers are pinned by hand-computed cases only (tests/test_eval_metrics.py) -- parity with pycocotools is UNPINNED.
+# ---------------------------------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+
+COCO_IOU_THRS = np.linspace(0.5, 0.95, 10)
+COCO_REC_THRS = np.linspace(0.0, 1.0, 101)
+COCO_AREAS = {"all": (0.0, 1e10), "small": (0.0, 32.0 ** 2), "medium": (32.0 ** 2, 96.0 ** 2), "large": (96.0 ** 2, 1e10)}
+
+
+def _iou_xywh(dt, gt, crowd):
+    """dt [D,4], gt [G,4] as (x, y, w, h), continuous extents; for crowd ground truth the union is the detection area."""
+    if dt.shape[0] == 0 or gt.shape[0] == 0:
+        return np.zeros((dt.shape[0], gt.shape[0]))
+    ix = np.minimum(dt[:, None, 0] + dt[:, None, 2], gt[None, :, 0] + gt[None, :, 2]) - np.maximum(dt[:, None, 0], gt[None, :, 0])
+    iy = np.minimum(dt[:, None, 1] + dt[:, None, 3], gt[None, :, 1] + gt[None, :, 3]) - np.maximum(dt[:, None, 1], gt[None, :, 1])
+    inter = np.clip(ix, 0, None) * np.clip(iy, 0, None)
+    da, ga = (dt[:, 2] * dt[:, 3])[:, None], (gt[:, 2] * gt[:, 3])[None, :]
+    union = np.where(np.asarray(crowd, bool)[None, :], da, da + ga - inter)
+    return inter / np.maximum(union, 1e-12)
+
+
+def _match_image(dt, gt_ig, crowd, ious, dt_area, area_rng):
+    """One image, one category, one area range. dt sorted by score desc; gts sorted non-ignored first.
+    Returns (matched [T,D] bool, dt_ignore [T,D] bool)."""
+    T, D, Gn = len(COCO_IOU_THRS), dt.shape[0], gt_ig.shape[0]
+    dtm = np.zeros((T, D), bool)
+    dtig = np.zeros((T, D), bool)
+    for ti, thr in enumerate(COCO_IOU_THRS):
+        gtm = np.zeros((Gn,), bool)
+        for d in range(D):
+            best, m = min(thr, 1 - 1e-10), -1
+            for g in range(Gn):
+                if gtm[g] and not crowd[g]:
+                    continue
+                if m > -1 and not gt_ig[m] and gt_ig[g]:
+                    break                                   # a real match exists: do not trade it for an ignored one
+                if ious[d, g] < best:
+                    continue
+                best, m = ious[d, g], g
+            if m == -1:
+                continue
+            dtm[ti, d], dtig[ti, d], gtm[m] = True, gt_ig[m], True
+    out = (dt_area < area_rng[0]) | (dt_area > area_rng[1])
+    dtig |= (~dtm) & out[None, :]
+    return dtm, dtig
+
+
+def coco_bbox_eval(gts, dts, max_dets=(1, 10, 100)):
+    """COCO box AP / AR.
+
+    gts: list of dicts {image_id, category_id, bbox [x,y,w,h], iscrowd (0/1, optional), area (optional)};
+    dts: list of dicts {image_id, category_id, bbox [x,y,w,h], score}.
+    Returns {"AP", "AP50", "AP75", "APs", "APm", "APl", "AR1", "AR10", "AR100", "ARs", "ARm", "ARl"} (-1 where undefined).
+    """
+    cats = sorted({g["category_id"] for g in gts} | {d["category_id"] for d in dts})
+    imgs = sorted({g["image_id"] for g in gts} | {d["image_id"] for d in dts})
+    G, Dd = {}, {}
+    for g in gts:
+        G.setdefault((g["image_id"], g["category_id"]), []).append(g)
+    for d in dts:
+        Dd.setdefault((d["image_id"], d["category_id"]), []).append(d)
+    T, R, K, A, M = len(COCO_IOU_THRS), len(COCO_REC_THRS), len(cats), len(COCO_AREAS), len(max_dets)
+    precision = -np.ones((T, R, K, A, M))
+    recall = -np.ones((T, K, A, M))
+    for ki, c in enumerate(cats):
+        for ai, rng in enumerate(COCO_AREAS.values()):
+            per_img = []
+            for im in imgs:
+                g, d = G.get((im, c), []), Dd.get((im, c), [])
+                if not g and not d:
+                    continue
+                gb = np.array([x["bbox"] for x in g], np.float64).reshape(-1, 4)
+                ga = np.array([x.get("area", x["bbox"][2] * x["bbox"][3]) for x in g], np.float64)
+                crowd = np.array([bool(x.get("iscrowd", 0)) for x in g], bool)
+                ig = crowd | (ga < rng[0]) | (ga > rng[1])
+                go = np.argsort(ig, kind="mergesort")
+                gb, crowd, ig = gb[go], crowd[go], ig[go]
+                do = np.argsort([-x["score"] for x in d], kind="mergesort")[:max_dets[-1]]
+                db = np.array([d[i]["bbox"] for i in do], np.float64).reshape(-1, 4)
+                sc = np.array([d[i]["score"] for i in do], np.float64)
+                dtm, dtig = _match_image(db, ig, crowd, _iou_xywh(db, gb, crowd), db[:, 2] * db[:, 3], rng)
+                per_img.append((sc, dtm, dtig, int((~ig).sum())))
+            if not per_img:
+                continue
+            npig = sum(p[3] for p in per_img)
+            if npig == 0:
+                continue
+            for mi, md in enumerate(max_dets):
+                sc = np.concatenate([p[0][:md] for p in per_img])
+                order = np.argsort(-sc, kind="mergesort")
+                dtm = np.concatenate([p[1][:, :md] for p in per_img], axis=1)[:, order]
+                dtig = np.concatenate([p[2][:, :md] for p in per_img], axis=1)[:, order]
+                tps = np.cumsum(dtm & ~dtig, axis=1).astype(np.float64)
+                fps = np.cumsum(~dtm & ~dtig, axis=1).astype(np.float64)
+                for ti in range(T):
+                    tp, fp = tps[ti], fps[ti]
+                    rc = tp / npig
+                    pr = tp / (fp + tp + np.spacing(1))
+                    recall[ti, ki, ai, mi] = rc[-1] if rc.size else 0.0
+                    for i in range(pr.size - 1, 0, -1):               # precision envelope
+                        if pr[i] > pr[i - 1]:
+                            pr[i - 1] = pr[i]
+                    q = np.zeros((R,))
+                    idx = np.searchsorted(rc, COCO_REC_THRS, side="left")
+                    ok = idx < pr.size
+                    q[ok] = pr[idx[ok]]
+                    precision[ti, :, ki, ai, mi] = q
+
+    def _ap(ai, ti=None):
+        p = precision[:, :, :, ai, M - 1] if ti is None else precision[ti, :, :, ai, M - 1]
+        p = p[p > -1]
+        return float(p.mean()) if p.size else -1.0
+
+    def _ar(ai, mi):
+        r = recall[:, :, ai, mi]
+        r = r[r > -1]
+        return float(r.mean()) if r.size else -1.0
+
+    names = list(COCO_AREAS)
+    out = {"AP": _ap(0), "AP50": _ap(0, 0), "AP75": _ap(0, 5), "APs": _ap(names.index("small")),
+           "APm": _ap(names.index("medium")), "APl": _ap(names.index("large"))}
+    for mi, md in enumerate(max_dets):
+        out["AR%d" % md] = _ar(0, mi)
+    out.update(ARs=_ar(1, M - 1), ARm=_ar(2, M - 1), ARl=_ar(3, M - 1))
+    return out
+
+
+def voc_ap(rec, prec, use_07_metric=False):
+    """VOC devkit average precision: 11-point (2007) or area under the monotone precision envelope."""
+    rec, prec = np.asarray(rec, np.float64), np.asarray(prec, np.float64)
+    if use_07_metric:
+        ap = 0.0
+        for t in np.arange(0.0, 1.1, 0.1):
+            ap += (prec[rec >= t].max() if np.any(rec >= t) else 0.0) / 11.0
+        return float(ap)
+    mrec = np.concatenate([[0.0], rec, [1.0]])
+    mpre = np.concatenate([[0.0], prec, [0.0]])
+    for i in range(mpre.size - 1, 0, -1):
+        mpre[i - 1] = max(mpre[i - 1], mpre[i])
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    return float(np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1]))
+
+
+def voc_eval(gts, dts, iou_thresh=0.5, use_07_metric=False):
+    """VOC mAP over classes. gts: {image_id, category_id, bbox [x1,y1,x2,y2] inclusive pixels, difficult (optional)};
+    dts: {image_id, category_id, bbox [x1,y1,x2,y2], score}. Returns (mAP, {category: AP})."""
+    aps = {}
+    for c in sorted({g["category_id"] for g in gts}):
+        gt_by_img = {}
+        for g in gts:
+            if g["category_id"] == c:
+                gt_by_img.setdefault(g["image_id"], []).append(g)
+        npos = sum(1 for gl in gt_by_img.values() for g in gl if not g.get("difficult", 0))
+        used = {im: np.zeros(len(gl), bool) for im, gl in gt_by_img.items()}
+        dl = sorted([d for d in dts if d["category_id"] == c], key=lambda d: -d["score"])
+        tp, fp = np.zeros(len(dl)), np.zeros(len(dl))
+        for i, d in enumerate(dl):
+            gl = gt_by_img.get(d["image_id"], [])
+            best, bj = -1.0, -1
+            bb = d["bbox"]
+            for j, g in enumerate(gl):
+                gb = g["bbox"]
+                iw = min(bb[2], gb[2]) - max(bb[0], gb[0]) + 1.0
+                ih = min(bb[3], gb[3]) - max(bb[1], gb[1]) + 1.0
+                if iw > 0 and ih > 0:
+                    ua = (bb[2] - bb[0] + 1.0) * (bb[3] - bb[1] + 1.0) + (gb[2] - gb[0] + 1.0) * (gb[3] - gb[1] + 1.0) - iw * ih
+                    if iw * ih / ua > best:
+                        best, bj = iw * ih / ua, j
+            if best > iou_thresh:
+                if gl[bj].get("difficult", 0):
+                    continue
+                if not used[d["image_id"]][bj]:
+                    tp[i], used[d["image_id"]][bj] = 1.0, True
+                else:
+                    fp[i] = 1.0
+            else:
+                fp[i] = 1.0
+        ctp, cfp = np.cumsum(tp), np.cumsum(fp)
+        rec = ctp / max(npos, 1)
+        prec = ctp / np.maximum(ctp + cfp, np.finfo(np.float64).eps)
+        aps[c] = voc_ap(rec, prec, use_07_metric) if npos else 0.0
+    return (float(np.mean(list(aps.values()))) if aps else 0.0), aps
+
+
+def detections_to_coco(dets, num_dets, image_ids, scales, class_to_cat=None):
+    """Device-side post-processing output -> COCO result dicts in ORIGINAL image coordinates.
+    dets [N,M,6] = (x1,y1,x2,y2,score,class) at network-input scale (inclusive corners), scales [N] = resize factors."""
+    dets = dets.detach().cpu().numpy() if hasattr(dets, "detach") else np.asarray(dets)
+    num = num_dets.detach().cpu().numpy() if hasattr(num_dets, "detach") else np.asarray(num_dets)
+    out = []
+    for n in range(dets.shape[0]):
+        for k in range(int(num[n])):
+            x1, y1, x2, y2, s, c = [float(v) for v in dets[n, k]]
+            x1, y1, x2, y2 = x1 / scales[n], y1 / scales[n], x2 / scales[n], y2 / scales[n]
+            cat = int(c) if class_to_cat is None else class_to_cat[int(c)]
+            out.append({"image_id": image_ids[n], "category_id": cat, "bbox": [x1, y1, x2 - x1 + 1.0, y2 - y1 + 1.0], "score": s})
+    return out

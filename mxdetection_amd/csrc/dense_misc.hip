@@ -337,7 +337,8 @@ __global__ void nhwc_to_nchw_kernel(const uint16_t* __restrict__ x, int N, int C
 // SGD with momentum over flat arenas; refreshes the bf16 working copy in the same pass
 __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                            uint16_t* __restrict__ wb, long long n, float lr, float mom, float wd,
-                           float rescale) {
+                           float rescale, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;      // scheduled learning rate: read at run time so that a captured graph follows it
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 4 <= n) {
@@ -509,6 +510,18 @@ extern "C" int mxdet_sgd_momentum_update(float* w, const float* grad, float* mom
   if (n == 0) return MXDET_OK;
   MXDET_REQUIRE(w && grad && mom, MXDET_EINVAL, "sgd_momentum_update: null pointer");
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(ceil_div<long long>(n, 4), 256)), dim3(256), 0,
-                     as_stream(stream), w, grad, mom, w_bf16, (long long)n, lr, momentum, wd, rescale);
+                     as_stream(stream), w, grad, mom, w_bf16, (long long)n, lr, momentum, wd, rescale, (const float*)nullptr);
   return check_launch("sgd_momentum_update");
+}
+
+extern "C" int mxdet_sgd_momentum_update_sched(float* w, const float* grad, float* mom, uint16_t* w_bf16, int64_t n,
+                                               const float* lr_dev, float momentum, float wd, float rescale,
+                                               mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(n >= 0, MXDET_ESHAPE, "sgd_momentum_update_sched: negative size");
+  if (n == 0) return MXDET_OK;
+  MXDET_REQUIRE(w && grad && mom && lr_dev, MXDET_EINVAL, "sgd_momentum_update_sched: null pointer");
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(ceil_div<long long>(n, 4), 256)), dim3(256), 0,
+                     as_stream(stream), w, grad, mom, w_bf16, (long long)n, 0.0f, momentum, wd, rescale, lr_dev);
+  return check_launch("sgd_momentum_update_sched");
 }

@@ -271,6 +271,8 @@ class DetectorBase:
         self.static_in = (image.clone(), gt_boxes.clone(), im_info.clone())
         self.static_masks = gt_masks.clone() if gt_masks is not None else None
         self.step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)   # replay(lr=...) rewrites it
+        self._lr_host = lr
         for i in range(warmup):     # eager warm-up: plans shapes and allocates every buffer
             self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr, gt_masks=self.static_masks)
         torch.cuda.synchronize()
@@ -284,7 +286,7 @@ class DetectorBase:
         if self.dist is not None and self._seen_buckets:
             # buckets seen in the eager warm-up: their transpose tables are built here, outside any capture
             self.opt_stream = torch.cuda.Stream()
-            self._cap_opt = (lr, 0.9, 1e-4)
+            self._cap_opt = (self.lr_dev, 0.9, 1e-4)
             for lo_hi in sorted(self._seen_buckets):
                 self._transpose_table(*lo_hi)
         side = torch.cuda.Stream()
@@ -292,11 +294,11 @@ class DetectorBase:
         with torch.cuda.stream(side):
             self._cap = True
             self._seg_begin()
-            self._upd, self._upd_done = ((lr, 0.9, 1e-4) if self.dist is None else None), []
+            self._upd, self._upd_done = ((self.lr_dev, 0.9, 1e-4) if self.dist is None else None), []
             losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
                                            gt_masks=self.static_masks)
             self._upd = None
-            self.optimizer_step(lr)
+            self.optimizer_step(self.lr_dev)
             self._seg_end()
             if self._final_join_opt:
                 self.segments.append(("join_opt",))
@@ -305,9 +307,12 @@ class DetectorBase:
         torch.cuda.synchronize()
         self.static_losses = losses
 
-    def replay(self, image, gt_boxes, im_info, step, gt_masks=None):
-        """One training step from the captured graphs."""
+    def replay(self, image, gt_boxes, im_info, step, gt_masks=None, lr=None):
+        """One training step from the captured graphs; lr (if given) replaces the captured learning rate from here on."""
         si = self.static_in
+        if lr is not None and lr != self._lr_host:
+            self.lr_dev.fill_(float(lr))
+            self._lr_host = lr
         if image is not si[0]:
             si[0].copy_(image, non_blocking=True)
             si[1].copy_(gt_boxes, non_blocking=True)

@@ -309,5 +309,10 @@ def nhwc_to_nchw(x):
 
 
 def sgd_momentum_update(w, grad, mom, w_bf16, lr, momentum=0.9, wd=1e-4, rescale=1.0):
+    """lr: python float, or a 1-element fp32 device tensor read when the kernel runs (scheduled lr under hipGraph replay)."""
+    if torch.is_tensor(lr):
+        check(_lib.load().mxdet_sgd_momentum_update_sched(ptr(w), ptr(grad), ptr(mom), ptr(w_bf16), w.numel(), ptr(lr),
+                                                          momentum, wd, rescale, stream_ptr()), "sgd_momentum_update_sched")
+        return
     check(_lib.load().mxdet_sgd_momentum_update(ptr(w), ptr(grad), ptr(mom), ptr(w_bf16), w.numel(), lr, momentum, wd,
                                                 rescale, stream_ptr()), "sgd_momentum_update")

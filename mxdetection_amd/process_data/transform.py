@@ -99,16 +99,26 @@ class BatchPreprocessor:
     """Decoded u8 frames (already on the device) -> normalised, padded bf16 NCHW batch in one launch."""
 
     def __init__(self, target_size=800, max_size=1333, means=PIXEL_MEANS, stds=PIXEL_STDS, swap_rb=False,
-                 pad_to=None, multiple=32):
-        self.target_size, self.max_size = target_size, max_size
+                 pad_to=None, multiple=32, fit_inside=False):
+        self.target_size, self.max_size, self.fit_inside = target_size, max_size, fit_inside
         self.means = (C.c_float * 3)(*means)
         self.stds = (C.c_float * 3)(*stds)
         self.swap_rb, self.pad_to, self.multiple = int(swap_rb), pad_to, multiple
 
     def plan(self, shapes):
         """[(h, w)] -> (scales, resized shapes, (Hp, Wp)). pad_to: None = smallest /multiple shape holding the batch,
-        (Hp, Wp) = fixed, "orient" = (800,1344)-style landscape or its transpose for portrait batches."""
+        (Hp, Wp) = fixed (with fit_inside: frames are scaled down to fit it), "orient" = (800,1344)-style landscape or
+        its transpose for portrait batches."""
         scales = [resize_scale(h, w, self.target_size, self.max_size) for (h, w) in shapes]
+        if self.fit_inside and isinstance(self.pad_to, tuple):
+            # one fixed batch shape for every frame (a single captured hipGraph): frames of the other orientation are
+            # scaled down until they fit -- a deviation from the lineage, which pads each batch to its own shape
+            hp, wp = self.pad_to
+            for n, (h, w) in enumerate(shapes):
+                s = min(scales[n], hp / float(h), wp / float(w))
+                while s > 0 and (int(round(h * s)) > hp or int(round(w * s)) > wp):
+                    s = s * (1.0 - 1e-6)
+                scales[n] = s
         rs = [resized_shape(h, w, s) for (h, w), s in zip(shapes, scales)]
         if self.pad_to == "orient":
             # two fixed shapes (landscape / portrait) so that a captured hipGraph per orientation can be replayed;

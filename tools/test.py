@@ -1,0 +1,54 @@
+"""Evaluation driver: checkpoint -> detections -> COCO box AP (the lineage's `test.py` role).
+
+    python tools/test.py --cfg configs/faster_rcnn_r50_fpn.yaml --params output/faster_rcnn_r50_fpn-0012.params
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", default=None)
+    ap.add_argument("--params", default="")
+    ap.add_argument("--max-images", type=int, default=0)
+    ap.add_argument("overrides", nargs="*")
+    args = ap.parse_args()
+    import torch
+    from mxdetection_amd.core.evaluation import coco_bbox_eval, detections_to_coco
+    from mxdetection_amd.models.builder import build_detector, build_loader
+    from mxdetection_amd.utils import load_config
+    cfg = load_config(args.cfg, list(args.overrides) + ["TRAIN.flip=false"])
+    assert cfg.network.type in ("faster_rcnn", "mask_rcnn"), "box evaluation is wired for the two-stage models"
+    model = build_detector(cfg)
+    if args.params:
+        model.load_checkpoint(args.params, strict=False)
+    roidb, _, loader = build_loader(cfg, train=False)
+    te = cfg.TEST
+    order = loader.rank_batches()
+    gts, dts, seen = [], [], set()
+    for k, batch in enumerate(loader):
+        dets, num = model.predict(batch["image"], batch["im_info"], te.score_thresh, te.nms, te.max_per_image)
+        ids = [int(i) for i in order[k]]
+        fresh = [n for n, i in enumerate(ids) if i not in seen]          # the last batch wraps around
+        scales = batch["im_info"][:, 2].cpu().numpy().tolist()
+        res = detections_to_coco(dets, num, [roidb[i]["id"] for i in ids], scales)
+        keep_ids = {roidb[ids[n]]["id"] for n in fresh}
+        dts += [r for r in res if r["image_id"] in keep_ids]
+        for n in fresh:
+            e = roidb[ids[n]]
+            seen.add(ids[n])
+            for b, c in zip(e["boxes"], e["gt_classes"]):
+                gts.append({"image_id": e["id"], "category_id": int(c), "bbox": [float(b[0]), float(b[1]), float(b[2] - b[0] + 1),
+                                                                               float(b[3] - b[1] + 1)]})
+        if args.max_images and len(seen) >= args.max_images:
+            break
+    torch.cuda.synchronize()
+    print(json.dumps({"images": len(seen), "detections": len(dts), **coco_bbox_eval(gts, dts)}))
+
+
+if __name__ == "__main__":
+    main()
