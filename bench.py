@@ -186,6 +186,12 @@ def main():
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
     from mxdetection_amd.models import FasterRCNN, RetinaNet
+    if os.environ.get("MXDET_WGRAD_CHUNK"):
+        from mxdetection_amd import _lib
+        _lib.load().mxdet_debug_wgrad_group_chunk(int(os.environ["MXDET_WGRAD_CHUNK"]))
+    if os.environ.get("MXDET_WGRAD_PERSIST"):
+        from mxdetection_amd import _lib
+        _lib.load().mxdet_debug_wgrad_group_persist(int(os.environ["MXDET_WGRAD_PERSIST"]))
     timer = ConvTimer()
     if not args.no_conv_timer:
         timer.install()

@@ -356,13 +356,17 @@ int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wg
 int mxdet_debug_force_conv_cfg(int32_t cfg);
 /* Tuning hook: force the split-K factor of mxdet_conv2d_wgrad on the calling thread (0 = heuristic). */
 int mxdet_debug_force_wgrad_ksplit(int32_t ksplit);
+/* tuning hook: issue a grouped weight-gradient launch in chunks of `workgroups` (0 = one launch) */
+int mxdet_debug_wgrad_group_chunk(int32_t workgroups);
+/* tuning hook: run grouped weight-gradient launches as a persistent grid of `workgroups` (rounded up to 8; 0 = off) */
+int mxdet_debug_wgrad_group_persist(int32_t workgroups);
 /* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);
 
 /* All filters of a model in one launch. descs_dev: device array of ndesc records
  * { const uint16_t* w; uint16_t* wt; int32 Cout, taps, Cin, tile0; } (32 bytes each) where tile0 is the running
- * sum of ceil(Cin/32)*ceil(Cout/32)*taps over the preceding records, total_tiles the overall sum. */
+ * sum of ceil(Cin/64)*ceil(Cout/64)*taps over the preceding records, total_tiles the overall sum. */
 int mxdet_filter_transpose_batched(const void* descs_dev, int32_t ndesc, int32_t total_tiles,
                                    mxdet_stream_t stream);
 

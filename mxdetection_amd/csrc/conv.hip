@@ -65,14 +65,19 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
-  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
+  // NS == 1 selects the half-stage pipeline (HP, see the main loop): two buffers whose 32-channel halves are refilled
+  // and consumed separately, fragments of the next half always read from LDS underneath the current half's MFMAs.
+  constexpr bool HP = (NS == 1);
+  constexpr int NBUF = HP ? 2 : NS;
+  constexpr int RPI = HP ? 16 : 8;                    // tile rows per LDS-DMA instruction (HP: 16 rows x 64 B)
+  constexpr int GA = BM / RPI / NW, GB = BN / RPI / NW;   // LDS-DMA instructions per wave per (half-)stage
   constexpr int STAGE = (BM + BN) * 64;               // bf16 elements per stage
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "rows must split evenly over the waves");
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "rows must split evenly over the waves");
   static_assert(MT % 2 == 0, "epilogue stages two m-tiles at a time");
-  static_assert(NS >= 2 && (NS - 2) * (GA + GB) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(HP || (NS >= 2 && (NS - 2) * (GA + GB) <= 63), "vmcnt is a 6-bit counter");
   constexpr int EP_STRIDE = WTN + 4;
   constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
-  constexpr int MAIN_BYTES = NS * STAGE * 2;
+  constexpr int MAIN_BYTES = NBUF * STAGE * 2;
   constexpr int SMEM_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
   __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
   uint16_t* smem = (uint16_t*)smem_raw;
@@ -112,16 +117,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   // The address math is hoisted out of the K loop (the loop was VALU-issue bound on it): per row a base
   // element offset and a bitmask of the taps that fall inside the image are computed once; inside the loop
   // a load costs one add + one bit test + one select, the per-tap displacement being a uniform SALU value.
-  const int lrow = lane >> 3, lslot = lane & 7;
+  // (HP: row 16j + (l>>2), 16-B slot l&3 of a 64-B half row; the swizzle uses two bits)
+  const int lrow = HP ? lane >> 2 : lane >> 3, lslot = HP ? lane & 3 : lane & 7;
+  constexpr int SWZ = HP ? 3 : 7;
   const unsigned short* zero = (const unsigned short*)g_zero_page;
   const int ntaps = p.KH * p.KW;
   int a_off[GA];
   unsigned a_mask[GA];
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
-    int ra = (wid * GA + i) * 8 + lrow;
+    int ra = (wid * GA + i) * RPI + lrow;
     int m = m0 + ra;
-    int coff = (lslot ^ ((ra >> 1) & 7)) << 3;
+    int coff = (lslot ^ ((ra >> 1) & SWZ)) << 3;
     unsigned mask = 0;
     int off = 0;
     if constexpr (PAR) {
@@ -170,10 +177,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const uint16_t* wrow[GB];
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
-    int rb = (wid * GB + i) * 8 + lrow;
+    int rb = (wid * GB + i) * RPI + lrow;
     int n = n0 + rb;
     n = n < p.Ncols ? n : p.Ncols - 1;   // rows past Ncols read a valid row; their columns are never stored
-    wrow[i] = p.w + (size_t)n * Ktot + ((lslot ^ ((rb >> 1) & 7)) << 3);
+    wrow[i] = p.w + (size_t)n * Ktot + ((lslot ^ ((rb >> 1) & SWZ)) << 3);
   }
 
   // running (channel-slice, tap) position of the NEXT stage to load: uniform scalars, no divisions
@@ -231,10 +238,132 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  const int frow = lane & 15, fq = lane >> 4;
+  if constexpr (HP) {
+    // ---- half-stage pipeline -------------------------------------------------------------------------------------
+    // Stage t lives in buffer t&1 as [A h0 | B h0 | A h1 | B h1] (h = 32-channel half, rows of 64 B). Step t:
+    //   barrier A: S(t)h1 landed everywhere, S(t)h0's fragments are in registers -> refill that region with S(t+2)h0;
+    //              MFMAs on S(t)h0 run while the fragments of S(t)h1 are read;
+    //   barrier B: S(t+1)h0 landed, S(t)h1's fragments are in registers -> refill with S(t+2)h1;
+    //              MFMAs on S(t)h1 run while the fragments of S(t+1)h0 are read.
+    // Every DMA has 1.5 steps to land, no fragment read is exposed behind a barrier (the plain ring reads the first
+    // half's fragments right after its barrier with the matrix pipes idle), LDS use equals the two-stage ring's.
+    constexpr int HALF = (BM + BN) * 32;            // bf16 elements per half-stage
+    constexpr int H = GA + GB;                      // DMA instructions per wave per half-stage
+    static_assert(3 * H <= 63, "vmcnt is a 6-bit counter");
+    auto issue_half = [&](int buf, int h) {
+      unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2) + (size_t)h * (HALF * 2);
+      const bool live = ld_kt < KT;
+      int tap, delta, koff;
+      if constexpr (PAR) {
+        tap = live ? ld_kh * nkw + ld_kw : 31;
+        delta = ld_c0 - (ld_kh * p.Ws + ld_kw) * p.C;
+        koff = live ? ((par_ph + 2 * ld_kh) * p.KW + (par_pw + 2 * ld_kw)) * p.C + ld_c0 : 0;
+      } else {
+        tap = live ? ld_kh * p.KW + ld_kw : 31;
+        if (DGRAD) delta = ld_c0 - ((ld_kh / p.stride) * p.Ws + (ld_kw / p.stride)) * p.C;
+        else delta = ld_c0 + (ld_kh * p.Ws + ld_kw) * p.C;
+        koff = live ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;
+      }
+      delta += h * 32;
+      koff += live ? h * 32 : 0;
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const unsigned short* src = ((a_mask[i] >> tap) & 1u) ? p.x + (a_off[i] + delta) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        const unsigned short* wsrc = wrow[i] + koff;
+        __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(sbase + BM * 64 + (wid * GB + i) * 1024), 16, 0, 0);
+      }
+      if (h == 1) {
+        ++ld_kt;
+        if (++ld_kw == nkw) {
+          ld_kw = 0;
+          if (++ld_kh == nkh) { ld_kh = 0; ld_c0 += 64; }
+        }
+      }
+    };
+    // element offsets of this lane's fragment rows inside a half (fixed for the whole loop)
+    int fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int r = wm * WTM + i * 16 + frow;
+      fa[i] = r * 32 + ((fq ^ ((r >> 1) & 3)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int r = wn * WTN + j * 16 + frow;
+      fb[j] = BM * 32 + r * 32 + ((fq ^ ((r >> 1) & 3)) << 3);
+    }
+    bf16x8_t x0a[MT], x0b[NT], x1a[MT], x1b[NT];
+    issue_half(0, 0);
+    issue_half(0, 1);
+    issue_half(1, 0);
+    issue_half(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * H) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MT; ++i) x0a[i] = *(const bf16x8_t*)(smem + fa[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) x0b[j] = *(const bf16x8_t*)(smem + fb[j]);
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      const uint16_t* s1 = smem + cur * STAGE + HALF;          // S(kt) second half
+      const uint16_t* s0n = smem + (cur ^ 1) * STAGE;          // S(kt+1) first half
+      // ---- phase 1 ----
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * H) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_half(cur, 0);
+      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) x1a[i] = *(const bf16x8_t*)(s1 + fa[i]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) x1b[j] = *(const bf16x8_t*)(s1 + fb[j]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0a[i], x0b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < MT + NT; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      // ---- phase 2 ----
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * H) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_half(cur, 1);
+      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) x0a[i] = *(const bf16x8_t*)(s0n + fa[i]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) x0b[j] = *(const bf16x8_t*)(s0n + fb[j]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1a[i], x1b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < MT + NT; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  } else {
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) issue_stage(s0);
 
-  const int frow = lane & 15, fq = lane >> 4;
   int cur = 0, nxt = NS - 1;
   for (int kt = 0; kt < KT; ++kt) {
     // stage kt has landed once all but the (NS-2) youngest stages' loads of this wave are done ...
@@ -286,6 +415,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     __builtin_amdgcn_s_setprio(0);
     cur = (cur + 1 == NS) ? 0 : cur + 1;
     nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail loads before LDS is re-used
   __syncthreads();
@@ -472,6 +602,13 @@ static int launch(ConvP& p, hipStream_t s) {
     case 15: return launch_cfg<256, 256, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 128x64 per wave, 128 KiB
     case 16: return launch_cfg<256, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 64x64 per wave, 96 KiB
     case 17: return launch_cfg<256, 128, 2, 2, 2, DGRAD>(p, s);   // 4 waves, 128x64 per wave, 96 KiB
+    // half-stage pipeline (NS = 1) variants
+    case 20: return launch_cfg<64, 64, 2, 2, 1, DGRAD>(p, s);
+    case 21: return launch_cfg<64, 128, 2, 2, 1, DGRAD>(p, s);
+    case 22: return launch_cfg<128, 128, 2, 2, 1, DGRAD>(p, s);
+    case 23: return launch_cfg<128, 64, 4, 1, 1, DGRAD>(p, s);
+    case 24: return launch_cfg<256, 256, 2, 4, 1, DGRAD>(p, s);
+    case 25: return launch_cfg<256, 128, 4, 2, 1, DGRAD>(p, s);
     default: break;
   }
   if constexpr (DGRAD) {

@@ -317,19 +317,27 @@ struct WgradG {
 
 template <int BKP, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
-  int lo = 0, hi = n - 1;
-  const int bid = (int)blockIdx.x;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace, int block_off,
+                     int total) {
+  // Persistent form: the grid may be smaller than the tile list (gridDim.x a multiple of 8 keeps logical tile -> XCD),
+  // each workgroup then walks tiles bid, bid + gridDim.x, ... A grid of one workgroup per CU places instantly and
+  // leaves the CU's other wave slots to the short dgrad kernels of the main stream, which a many-round grid would
+  // keep waiting until its last workgroup has been placed.
+  for (int bid = (int)blockIdx.x + block_off; bid < total; bid += (int)gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int b = bid - table[lo].block0;
+    if (b < table[lo].nblocks) {                     // else: alignment padding between layers
+      WgradP p = table[lo].p;
+      p.slab = (float*)(workspace + (size_t)p.slab);
+      p.bslab = (float*)(workspace + (size_t)p.bslab);
+      wgrad_tile<BKP, NS>(p, b);
+    }
+    __syncthreads();                                 // LDS ring is reused by the next tile
   }
-  const int b = bid - table[lo].block0;
-  if (b >= table[lo].nblocks) return;            // alignment padding between layers
-  WgradP p = table[lo].p;
-  p.slab = (float*)(workspace + (size_t)p.slab);
-  p.bslab = (float*)(workspace + (size_t)p.bslab);
-  wgrad_tile<BKP, NS>(p, b);
 }
 
 // dw[i] (+)= sum_ks slab[ks][i] in index order; the trailing workgroups fold the bias partials the same way.
@@ -445,9 +453,13 @@ __global__ void filter_transpose_kernel(const uint16_t* __restrict__ w, int Cout
 
 // batched form: one launch for every filter of the model (descriptor table in device memory)
 struct TransposeDesc { const uint16_t* w; uint16_t* wt; int Cout, taps, Cin, tile0; };
-__global__ void filter_transpose_batched_kernel(const TransposeDesc* __restrict__ descs, int ndesc) {
-  __shared__ uint16_t tile[32][33];
-  // binary search the descriptor that owns this tile
+__global__ void __launch_bounds__(256)
+filter_transpose_batched_kernel(const TransposeDesc* __restrict__ descs, int ndesc) {
+  // 64 (co) x 64 (ci) tile per workgroup: 16-byte global loads along ci, 16-byte global stores along co. LDS pitch 66
+  // halfwords: the column gathers of the store phase (lanes = 8 ci x 8 co-groups) fall on 32 distinct banks, two lanes
+  // per bank reading the same dword.
+  __shared__ uint32_t tile32[64 * 33];
+  uint16_t* tile = (uint16_t*)tile32;
   int lo = 0, hi = ndesc - 1;
   const int b = blockIdx.x;
   while (lo < hi) {
@@ -456,21 +468,48 @@ __global__ void filter_transpose_batched_kernel(const TransposeDesc* __restrict_
   }
   const TransposeDesc d = descs[lo];
   int t = b - d.tile0;
-  const int tiles_ci = (d.Cin + 31) >> 5, tiles_co = (d.Cout + 31) >> 5;
+  const int tiles_ci = (d.Cin + 63) >> 6, tiles_co = (d.Cout + 63) >> 6;
   const int tci = t % tiles_ci; t /= tiles_ci;
   const int tco = t % tiles_co; t /= tiles_co;
   const int tap = t;
-  const int ci0 = tci * 32, co0 = tco * 32;
-  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-    int co = co0 + r, ci = ci0 + threadIdx.x;
-    uint16_t v = 0;
-    if (co < d.Cout && ci < d.Cin) v = d.w[((size_t)co * d.taps + tap) * d.Cin + ci];
-    tile[r][threadIdx.x] = v;
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const bool vec = ((d.Cin | d.Cout) & 7) == 0 && ((((uintptr_t)d.w) | ((uintptr_t)d.wt)) & 15) == 0;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int c = tid; c < 512; c += 256) {
+    const int r = c >> 3, k = (c & 7) * 8;
+    const int co = co0 + r, ci = ci0 + k;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (co < d.Cout && ci < d.Cin) {
+      const uint16_t* src = d.w + ((size_t)co * d.taps + tap) * d.Cin + ci;
+      if (vec) {
+        const uint4 q = *(const uint4*)src;
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+        for (int j = 0; j < 8; ++j)
+          if (ci + j < d.Cin) v[j >> 1] |= (uint32_t)src[j] << (16 * (j & 1));
+      }
+    }
+    uint32_t* dst = tile32 + r * 33 + (k >> 1);
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
   }
   __syncthreads();
-  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-    int ci = ci0 + r, co = co0 + threadIdx.x;
-    if (co < d.Cout && ci < d.Cin) d.wt[((size_t)ci * d.taps + tap) * d.Cout + co] = tile[threadIdx.x][r];
+#pragma unroll
+  for (int c = tid; c < 512; c += 256) {
+    const int r = c >> 3, k = (c & 7) * 8;        // r: ci within the tile, k: first of 8 co
+    const int ci = ci0 + r, co = co0 + k;
+    if (ci >= d.Cin || co >= d.Cout) continue;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      v[j] = (uint32_t)tile[(k + 2 * j) * 66 + r] | ((uint32_t)tile[(k + 2 * j + 1) * 66 + r] << 16);
+    uint16_t* dst = d.wt + ((size_t)ci * d.taps + tap) * d.Cout + co;
+    if (vec) {
+      *(uint4*)dst = make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int j = 0; j < 8; ++j)
+        if (co + j < d.Cout) dst[j] = (uint16_t)(v[j >> 1] >> (16 * (j & 1)));
+    }
   }
 }
 
@@ -479,6 +518,8 @@ struct WgradPlan {
   size_t slab_bytes, bslab_off, bslab_bytes, total;
 };
 
+static int g_group_persist = 0;               // tuning hook (mxdet_debug_wgrad_group_persist), 0 = one workgroup per tile
+static int g_group_chunk = 0;                 // tuning hook (mxdet_debug_wgrad_group_chunk), 0 = one launch per group
 static thread_local int g_force_ksplit = 0;   // tuning hook (mxdet_debug_force_wgrad_ksplit), 0 = heuristic
 
 static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
@@ -511,6 +552,16 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
 }  // namespace mxdet
 
 using namespace mxdet;
+
+extern "C" int mxdet_debug_wgrad_group_persist(int32_t workgroups) {
+  g_group_persist = workgroups;
+  return MXDET_OK;
+}
+
+extern "C" int mxdet_debug_wgrad_group_chunk(int32_t workgroups) {
+  g_group_chunk = workgroups;
+  return MXDET_OK;
+}
 
 extern "C" int mxdet_debug_force_wgrad_ksplit(int32_t ks) {
   g_force_ksplit = ks;
@@ -698,8 +749,17 @@ extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int3
   MXDET_REQUIRE(workspace_needed == 0 || (workspace && workspace_bytes >= workspace_needed), MXDET_EWORKSPACE,
                 "wgrad_grouped: workspace %zu < %zu", workspace_bytes, workspace_needed);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid_wgrad), dim3(256), 0, s,
-                     (const WgradG*)table_dev, n, (unsigned char*)workspace);
+  // Optional chunking (tuning hook): a grid far larger than one resident round keeps the dispatcher on this queue until
+  // it has placed every workgroup, which starves the short dgrad kernels of the main stream; chunks of about one
+  // resident round let the two queues alternate at launch granularity.
+  const int chunk = g_group_chunk > 0 ? g_group_chunk : grid_wgrad;
+  const int persist = g_group_persist > 0 ? (g_group_persist + 7) & ~7 : 0;
+  for (int off = 0; off < grid_wgrad; off += chunk) {
+    const int cnt = grid_wgrad - off < chunk ? grid_wgrad - off : chunk;
+    const int grid = persist > 0 && persist < cnt ? persist : cnt;
+    hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
+                       (unsigned char*)workspace, off, off + cnt);
+  }
   if (grid_reduce > 0)
     hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)grid_reduce), dim3(256), 0, s,
                        (const WgradG*)table_dev, n, (const unsigned char*)workspace);
@@ -711,7 +771,7 @@ extern "C" int mxdet_filter_transpose_batched(const void* descs_dev, int32_t nde
   clear_error();
   MXDET_REQUIRE(ndesc > 0 && total_tiles > 0, MXDET_ESHAPE, "filter_transpose_batched: empty table");
   MXDET_REQUIRE(descs_dev != nullptr, MXDET_EINVAL, "filter_transpose_batched: null pointer");
-  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3(total_tiles), dim3(32, 8), 0, as_stream(stream),
+  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream),
                      (const TransposeDesc*)descs_dev, ndesc);
   return check_launch("filter_transpose_batched");
 }

@@ -184,7 +184,7 @@ def make_transpose_table(pairs, device):
     for w, wt in pairs:
         Cout, KH, KW, Cin = w.shape
         buf += struct.pack("<QQiiii", w.data_ptr(), wt.data_ptr(), Cout, KH * KW, Cin, tile0)
-        tile0 += ((Cin + 31) // 32) * ((Cout + 31) // 32) * KH * KW
+        tile0 += ((Cin + 63) // 64) * ((Cout + 63) // 64) * KH * KW
     table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
     return table, len(pairs), tile0
 

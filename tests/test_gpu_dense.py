@@ -303,3 +303,20 @@ def test_grouped_conv_and_wgrad_match_single_launches(hip, oracle):
     # strided data gradients are refused by the grouped plan (they have their own parity-grouped kernel)
     with pytest.raises(hip.MxdetError):
         dense.GroupedConv("dgrad", [(dys[1], wt, (2, 25, 42, Cin), K, K, 2, 1, None, None, False, outd[0])] * 2, "cuda")
+
+
+def test_filter_transpose_batched_matches_permute(hip):
+    """All filters of a model in one launch: 64x64 tiles, 16-byte accesses, scalar path for odd channel counts."""
+    import torch
+    from mxdetection_amd.ops import dense
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 3, 3, 256), (1024, 1, 1, 256), (64, 1, 1, 192), (448, 1, 1, 1024), (81, 1, 1, 100), (72, 3, 3, 40), (8, 1, 1, 8)]
+    pairs = []
+    for co, kh, kw, ci in shapes:
+        w = torch.randn((co, kh, kw, ci), generator=g).to(torch.bfloat16).cuda()
+        pairs.append((w, torch.full((ci, kh, kw, co), 7.0, dtype=torch.bfloat16, device="cuda")))
+    table = dense.make_transpose_table(pairs, "cuda")
+    dense.filter_transpose_batched(*table)
+    torch.cuda.synchronize()
+    for w, wt in pairs:
+        assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())

@@ -9,7 +9,8 @@ from mxdetection_amd.ops import dense
 lib = _lib.load()
 cfgs = [int(c) for c in sys.argv[1:]] or [20, 22]
 shapes = [(2, 50, 84, 256, 256, 3, 1), (2, 25, 42, 512, 512, 3, 1), (2, 25, 42, 2048, 512, 1, 1), (2, 25, 42, 512, 2048, 1, 1),
-          (2, 50, 84, 1024, 256, 1, 1), (2, 50, 84, 256, 1024, 1, 1), (1, 13, 21, 192, 200, 3, 1), (2, 100, 168, 128, 128, 3, 1)]
+          (2, 50, 84, 1024, 256, 1, 1), (2, 50, 84, 256, 1024, 1, 1), (1, 13, 21, 192, 200, 3, 1), (2, 100, 168, 128, 128, 3, 1),
+          (2, 200, 336, 256, 256, 3, 1), (2, 200, 336, 64, 256, 1, 1), (2, 100, 168, 512, 128, 1, 1)]
 def timeit(fn, reps=20):
     fn(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
