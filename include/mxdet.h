@@ -273,6 +273,15 @@ size_t mxdet_mask_loss_workspace_bytes(int64_t R, int32_t S);
 int mxdet_mask_loss(const uint16_t* logits, const int32_t* cls, const uint8_t* targets, int64_t R, int32_t S,
                     int32_t Cpad, float loss_scale, float* loss_out, uint16_t* grad, void* workspace,
                     size_t workspace_bytes, mxdet_stream_t stream);
+/* Inference paste-back (MXNet-lineage role: sigmoid -> cv2.resize(mask, (w, h)) -> > 0.5 -> place at the box, on the
+ * host). dets [R,6] = (x1,y1,x2,y2,score,class) in the frame of the OUTPUT masks; logits [R,S,S,Cpad] bf16.
+ * prob = sigmoid(logit of channel class-1); box corners rounded half-even to integers, w = x2-x1+1, h = y2-y1+1;
+ * pixel (x,y) inside the box samples prob bilinearly at ((x-x1+0.5)*S/w-0.5, (y-y1+0.5)*S/h-0.5) (clamped, fp32,
+ * unfused: top/bottom rows first, then vertical) and is 1 where the value > thresh. masks [R,H,W] u8, W % 4 == 0;
+ * rows with class <= 0 are all zero. */
+size_t mxdet_mask_paste_workspace_bytes(int64_t R, int32_t S);
+int mxdet_mask_paste(const uint16_t* logits, const float* dets, int64_t R, int32_t S, int32_t Cpad, int32_t H, int32_t W,
+                     float thresh, uint8_t* masks, void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * backbones / necks / rpn_heads / bbox_heads / mask_heads (README.md:27-31) -- dense contractions.

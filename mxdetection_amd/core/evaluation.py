@@ -101,7 +101,25 @@ def _match_image(dt, gt_ig, crowd, ious, dt_area, area_rng):
     return dtm, dtig
 
 
-def coco_bbox_eval(gts, dts, max_dets=(1, 10, 100)):
+def _iou_masks(dm, gm, crowd):
+    """dm [D,H,W], gm [G,H,W] binary masks in one frame; for crowd ground truth the union is the detection area."""
+    if dm.shape[0] == 0 or gm.shape[0] == 0:
+        return np.zeros((dm.shape[0], gm.shape[0]))
+    d = dm.reshape(dm.shape[0], -1).astype(np.float32)
+    g = gm.reshape(gm.shape[0], -1).astype(np.float32)
+    inter = (d @ g.T).astype(np.float64)
+    da, ga = d.sum(1).astype(np.float64)[:, None], g.sum(1).astype(np.float64)[None, :]
+    union = np.where(np.asarray(crowd, bool)[None, :], da, da + ga - inter)
+    return inter / np.maximum(union, 1e-12)
+
+
+def coco_segm_eval(gts, dts, max_dets=(1, 10, 100)):
+    """COCO mask AP / AR: same protocol as coco_bbox_eval with mask IoU. Every entry carries "mask" (binary [H,W] array in
+    the image's frame); areas are mask areas unless the ground truth gives "area"."""
+    return coco_bbox_eval(gts, dts, max_dets, _segm=True)
+
+
+def coco_bbox_eval(gts, dts, max_dets=(1, 10, 100), _segm=False):
     """COCO box AP / AR.
 
     gts: list of dicts {image_id, category_id, bbox [x,y,w,h], iscrowd (0/1, optional), area (optional)};
@@ -125,16 +143,26 @@ def coco_bbox_eval(gts, dts, max_dets=(1, 10, 100)):
                 g, d = G.get((im, c), []), Dd.get((im, c), [])
                 if not g and not d:
                     continue
-                gb = np.array([x["bbox"] for x in g], np.float64).reshape(-1, 4)
-                ga = np.array([x.get("area", x["bbox"][2] * x["bbox"][3]) for x in g], np.float64)
+                if _segm:
+                    shp = (g[0] if g else d[0])["mask"].shape
+                    gb = np.array([np.asarray(x["mask"]) > 0 for x in g], bool).reshape((-1,) + shp)
+                    ga = np.array([x.get("area", float((np.asarray(x["mask"]) > 0).sum())) for x in g], np.float64)
+                else:
+                    gb = np.array([x["bbox"] for x in g], np.float64).reshape(-1, 4)
+                    ga = np.array([x.get("area", x["bbox"][2] * x["bbox"][3]) for x in g], np.float64)
                 crowd = np.array([bool(x.get("iscrowd", 0)) for x in g], bool)
                 ig = crowd | (ga < rng[0]) | (ga > rng[1])
                 go = np.argsort(ig, kind="mergesort")
                 gb, crowd, ig = gb[go], crowd[go], ig[go]
                 do = np.argsort([-x["score"] for x in d], kind="mergesort")[:max_dets[-1]]
-                db = np.array([d[i]["bbox"] for i in do], np.float64).reshape(-1, 4)
                 sc = np.array([d[i]["score"] for i in do], np.float64)
-                dtm, dtig = _match_image(db, ig, crowd, _iou_xywh(db, gb, crowd), db[:, 2] * db[:, 3], rng)
+                if _segm:
+                    db = np.array([np.asarray(d[i]["mask"]) > 0 for i in do], bool).reshape((-1,) + shp)
+                    ious, darea = _iou_masks(db, gb, crowd), db.reshape(db.shape[0], -1).sum(1).astype(np.float64)
+                else:
+                    db = np.array([d[i]["bbox"] for i in do], np.float64).reshape(-1, 4)
+                    ious, darea = _iou_xywh(db, gb, crowd), db[:, 2] * db[:, 3]
+                dtm, dtig = _match_image(db, ig, crowd, ious, darea, rng)
                 per_img.append((sc, dtm, dtig, int((~ig).sum())))
             if not per_img:
                 continue

@@ -31,3 +31,18 @@ def mask_loss(logits, cls, targets, loss_out, grad, workspace, loss_scale=1.0):
     check(lib.mxdet_mask_loss(ptr(logits), ptr(cls), ptr(targets), R, S, Cpad, loss_scale, ptr(loss_out), ptr(grad),
                               ptr(workspace), workspace.numel(), stream_ptr()), "mask_loss")
     return loss_out
+
+
+def mask_paste(logits, dets, H, W, thresh=0.5, out=None, workspace=None):
+    """Inference paste-back: logits bf16 [R,S,S,Cpad], dets [R,6] f32 (x1,y1,x2,y2,score,class) in the output frame
+    -> full-frame instance masks [R,H,W] u8 (mxdet_mask_paste)."""
+    lib = _lib.load()
+    R, S, _, Cpad = logits.shape
+    need = lib.mxdet_mask_paste_workspace_bytes(R, S)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=logits.device)
+    if out is None:
+        out = torch.empty((R, H, W), dtype=torch.uint8, device=logits.device)
+    check(lib.mxdet_mask_paste(ptr(logits), ptr(dets), R, S, Cpad, H, W, thresh, ptr(out), ptr(workspace), workspace.numel(),
+                               stream_ptr()), "mask_paste")
+    return out

@@ -125,6 +125,69 @@ mask_finalize_kernel(const float* __restrict__ partial, int count, float* __rest
   if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// ---- mask paste-back (inference): class channel -> probability map -> bilinear resize into the detection box -> threshold
+// prob[r][i] = sigmoid(logits[r, i, cls-1]) for the detection's class (rows without a valid class give zeros)
+__global__ void __launch_bounds__(256)
+mask_prob_kernel(const uint16_t* __restrict__ logits, const float* __restrict__ dets, int R, int SS, int Cpad,
+                 float* __restrict__ prob) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)R * SS) return;
+  const int r = (int)(i / SS);
+  const int c = (int)dets[r * 6 + 5];
+  float pv = 0.0f;
+  if (c > 0 && c <= Cpad) {
+    const float z = bf16_bits_to_f32(logits[i * Cpad + (c - 1)]);
+    pv = z >= 0.0f ? 1.0f / (1.0f + mxdet_expf(-z)) : mxdet_expf(z) / (1.0f + mxdet_expf(z));
+  }
+  prob[i] = pv;
+}
+
+// source coordinate of destination index d when S samples are stretched over `len` pixels (OpenCV float bilinear:
+// half-pixel centres, clamped at both ends)
+__device__ __forceinline__ void paste_coef(int d, int len, int S, int& s0, int& s1, float& f) {
+  float x = (float)(((double)d + 0.5) * ((double)S / (double)len) - 0.5);
+  int s = (int)floorf(x);
+  x -= (float)s;
+  if (s < 0) { x = 0.0f; s = 0; }
+  if (s >= S - 1) { x = 0.0f; s = S - 1; }
+  s0 = s;
+  s1 = s + 1 < S ? s + 1 : S - 1;
+  f = x;
+}
+
+// one lane = 4 consecutive pixels of one row of one detection's full-frame mask (one 32-bit store)
+__global__ void __launch_bounds__(256)
+mask_paste_kernel(const float* __restrict__ prob, const float* __restrict__ dets, int S, int H, int W, float thresh,
+                  uint8_t* __restrict__ out) {
+  const int r = blockIdx.z, y = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x0 >= W) return;
+  const float* d = dets + r * 6;
+  // integer box, inclusive corners, as the lineage rounds it before resizing the mask into it
+  const int bx1 = (int)rintf(d[0]), by1 = (int)rintf(d[1]), bx2 = (int)rintf(d[2]), by2 = (int)rintf(d[3]);
+  const int bw = bx2 - bx1 + 1, bh = by2 - by1 + 1;
+  unsigned wbits = 0u;
+  if ((int)d[5] > 0 && bw > 0 && bh > 0 && y >= by1 && y <= by2) {
+    int sy0, sy1;
+    float fy;
+    paste_coef(y - by1, bh, S, sy0, sy1, fy);
+    const float* p = prob + (long long)r * S * S;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = x0 + j;
+      if (x < bx1 || x > bx2) continue;
+      int sx0, sx1;
+      float fx;
+      paste_coef(x - bx1, bw, S, sx0, sx1, fx);
+      const float top = __fadd_rn(__fmul_rn(p[sy0 * S + sx0], __fsub_rn(1.0f, fx)), __fmul_rn(p[sy0 * S + sx1], fx));
+      const float bot = __fadd_rn(__fmul_rn(p[sy1 * S + sx0], __fsub_rn(1.0f, fx)), __fmul_rn(p[sy1 * S + sx1], fx));
+      const float v = __fadd_rn(__fmul_rn(top, __fsub_rn(1.0f, fy)), __fmul_rn(bot, fy));
+      if (v > thresh) wbits |= 1u << (8 * j);
+    }
+  }
+  *(unsigned*)(out + ((long long)r * H + y) * W + x0) = wbits;
+}
+
 }  // namespace mxdet
 
 using namespace mxdet;
@@ -177,4 +240,29 @@ extern "C" int mxdet_mask_loss(const uint16_t* logits, const int32_t* cls, const
                      (const int*)cnt, loss_scale, grad, partial);
   hipLaunchKernelGGL(mask_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, blocks, loss_out);
   return check_launch("mask_loss");
+}
+
+extern "C" size_t mxdet_mask_paste_workspace_bytes(int64_t R, int32_t S) {
+  return (size_t)(R > 0 ? R : 0) * S * S * sizeof(float) + 256;
+}
+
+extern "C" int mxdet_mask_paste(const uint16_t* logits, const float* dets, int64_t R, int32_t S, int32_t Cpad, int32_t H,
+                                int32_t W, float thresh, uint8_t* masks, void* workspace, size_t workspace_bytes,
+                                mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(R >= 0 && S > 0 && Cpad > 0 && H > 0 && W > 0 && W % 4 == 0, MXDET_ESHAPE,
+                "mask_paste: bad shape (W must be a multiple of 4)");
+  if (R == 0) return MXDET_OK;
+  MXDET_REQUIRE(R <= 65535 && H <= 65535, MXDET_ESHAPE, "mask_paste: R=%lld or H=%d exceeds the grid", (long long)R, H);
+  MXDET_REQUIRE(logits && dets && masks, MXDET_EINVAL, "mask_paste: null pointer");
+  MXDET_REQUIRE(workspace && workspace_bytes >= mxdet_mask_paste_workspace_bytes(R, S), MXDET_EWORKSPACE,
+                "mask_paste: workspace too small");
+  hipStream_t s = as_stream(stream);
+  float* prob = (float*)workspace;
+  const long long n = (long long)R * S * S;
+  hipLaunchKernelGGL(mask_prob_kernel, dim3((unsigned)ceil_div<long long>(n, 256)), dim3(256), 0, s, logits, dets, (int)R,
+                     S * S, Cpad, prob);
+  hipLaunchKernelGGL(mask_paste_kernel, dim3((unsigned)ceil_div(W, 1024), (unsigned)H, (unsigned)R), dim3(256), 0, s, prob,
+                     dets, S, H, W, thresh, masks);
+  return check_launch("mask_paste");
 }

@@ -135,10 +135,12 @@ class FasterRCNN(DetectorBase):
             return rpn_loss, rcnn_loss, mask_loss
         return rpn_loss, rcnn_loss
 
-    def predict(self, image, im_info, score_thresh=0.05, nms_thresh=0.5, max_per_image=100):
+    def predict(self, image, im_info, score_thresh=0.05, nms_thresh=0.5, max_per_image=100, with_masks=False,
+                mask_thresh=0.5):
         """Inference: forward, proposals, box head, then softmax / decode / per-class NMS / top-k on the GPU
         (core/evaluation, SURVEY.md section 8f rank 3). Returns (dets [N,max_per_image,6] = x1,y1,x2,y2,score,class;
-        num_dets [N])."""
+        num_dets [N]); with_masks (Mask R-CNN) adds the pasted-back instance masks [N,max_per_image,H,W] u8 in the
+        frame of the network input: mask head on the detected boxes, sigmoid, bilinear resize into the box, threshold."""
         from ..core.evaluation import DetectionPostprocess
         N, _, H, W = image.shape
         g_max = self.planned[3] if self.planned is not None and self.planned[:3] == (N, H, W) else 100
@@ -154,7 +156,20 @@ class FasterRCNN(DetectorBase):
             self._post = DetectionPostprocess(self.bbox_head.nc, score_thresh, nms_thresh, max_per_image,
                                               stds=self.bbox_head.stds)
             self._post_key = key
-        return self._post(o2[:, :self.bbox_head.nc], o2[:, self.bbox_head.nc:], rois.view(-1, 5), num_rois, im_info)
+        dets, num = self._post(o2[:, :self.bbox_head.nc], o2[:, self.bbox_head.nc:], rois.view(-1, 5), num_rois, im_info)
+        if not with_masks:
+            return dets, num
+        assert self.with_mask, "with_masks needs a model built with the mask head"
+        from ..core import mask as M_
+        M = dets.shape[1]
+        flat = dets.view(N * M, 6)
+        drois = torch.empty((N * M, 5), dtype=torch.float32, device=dets.device)
+        drois[:, 0] = torch.arange(N, device=dets.device, dtype=torch.float32).repeat_interleave(M)
+        drois[:, 1:] = flat[:, :4]            # padding rows are zero boxes with class -1: pasted as empty masks
+        mpooled = self.mask_roi_extractor.forward(P, drois)
+        logits = self.mask_head.forward(mpooled)
+        masks = M_.mask_paste(logits, flat, H, W, mask_thresh)
+        return dets, num, masks.view(N, M, H, W)
 
     def _backbone_stage_backward(self, si):
         stage = self.backbone.stages[si]

@@ -936,3 +936,41 @@ API void oracle_polygon_masks(const float* verts, const int32_t* poly_start, con
       }
     }
 }
+
+/* core/mask inference paste-back: see include/mxdet.h mxdet_mask_paste. logits [R][S][S][Cpad] f32 (bf16-valued). */
+static void o_paste_coef(int d, int len, int S, int* s0, int* s1, float* f) {
+  float x = (float)(((double)d + 0.5) * ((double)S / (double)len) - 0.5);
+  int s = (int)floorf(x);
+  x -= (float)s;
+  if (s < 0) { x = 0.0f; s = 0; }
+  if (s >= S - 1) { x = 0.0f; s = S - 1; }
+  *s0 = s; *s1 = s + 1 < S ? s + 1 : S - 1; *f = x;
+}
+API void oracle_mask_paste(const float* logits, const float* dets, int R, int S, int Cpad, int H, int W, float thresh,
+                           uint8_t* masks) {
+  float* p = (float*)malloc(sizeof(float) * (size_t)S * S);
+  for (int r = 0; r < R; ++r) {
+    uint8_t* out = masks + (size_t)r * H * W;
+    memset(out, 0, (size_t)H * W);
+    const float* d = dets + (size_t)r * 6;
+    const int c = (int)d[5];
+    if (!(c > 0 && c <= Cpad)) continue;
+    for (int i = 0; i < S * S; ++i) p[i] = o_sigmoid(logits[((size_t)r * S * S + i) * Cpad + (c - 1)]);
+    const int bx1 = (int)rintf(d[0]), by1 = (int)rintf(d[1]), bx2 = (int)rintf(d[2]), by2 = (int)rintf(d[3]);
+    const int bw = bx2 - bx1 + 1, bh = by2 - by1 + 1;
+    if (bw <= 0 || bh <= 0) continue;
+    for (int y = by1 < 0 ? 0 : by1; y <= by2 && y < H; ++y) {
+      int sy0, sy1; float fy;
+      o_paste_coef(y - by1, bh, S, &sy0, &sy1, &fy);
+      for (int x = bx1 < 0 ? 0 : bx1; x <= bx2 && x < W; ++x) {
+        int sx0, sx1; float fx;
+        o_paste_coef(x - bx1, bw, S, &sx0, &sx1, &fx);
+        const float top = p[sy0 * S + sx0] * (1.0f - fx) + p[sy0 * S + sx1] * fx;
+        const float bot = p[sy1 * S + sx0] * (1.0f - fx) + p[sy1 * S + sx1] * fx;
+        const float v = top * (1.0f - fy) + bot * fy;
+        out[(size_t)y * W + x] = v > thresh ? 1 : 0;
+      }
+    }
+  }
+  free(p);
+}

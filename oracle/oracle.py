@@ -383,3 +383,13 @@ def polygon_masks(verts, poly_start, inst_first, NG, H, W):
     masks = np.zeros((NG, H, W), np.uint8)
     lib().oracle_polygon_masks(_vp(verts), _vp(poly_start), _vp(inst_first), C.c_int(NG), C.c_int(H), C.c_int(W), _vp(masks))
     return masks
+
+
+def mask_paste(logits, dets, H, W, thresh=0.5):
+    """logits [R,S,S,Cpad] f32 (bf16-valued), dets [R,6] -> masks [R,H,W] u8."""
+    logits, dets = _c(logits, np.float32), _c(dets, np.float32)
+    R, S, _, Cpad = logits.shape
+    masks = np.zeros((R, H, W), np.uint8)
+    lib().oracle_mask_paste(_vp(logits), _vp(dets), C.c_int(R), C.c_int(S), C.c_int(Cpad), C.c_int(H), C.c_int(W),
+                            C.c_float(thresh), _vp(masks))
+    return masks

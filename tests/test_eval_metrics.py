@@ -76,3 +76,26 @@ def test_detections_to_coco_rescales():
     dets[0, 0] = (20, 40, 119, 79, 0.7, 3)
     out = detections_to_coco(dets, np.array([1]), [42], [2.0], class_to_cat={3: 18})
     assert out == [{"image_id": 42, "category_id": 18, "bbox": [10.0, 20.0, 50.5, 20.5], "score": pytest.approx(0.7)}]
+
+
+def test_segm_eval_known_answers():
+    from mxdetection_amd.core.evaluation import coco_segm_eval
+    H, W = 64, 64
+
+    def rect(x1, y1, x2, y2):
+        m = np.zeros((H, W), np.uint8)
+        m[y1:y2, x1:x2] = 1
+        return m
+    gts = [dict(image_id=1, category_id=1, mask=rect(0, 0, 40, 40)), dict(image_id=1, category_id=2, mask=rect(10, 40, 60, 60))]
+    dts = [dict(image_id=1, category_id=1, mask=rect(0, 0, 40, 40), score=0.9), dict(image_id=1, category_id=2, mask=rect(10, 40, 60, 60), score=0.8)]
+    assert coco_segm_eval(gts, dts)["AP"] == pytest.approx(1.0)
+    # mask IoU 2/3 (40x32 of a 40x40 object, shifted by 8): matches at IoU 0.50..0.65 only, like the box case
+    dts[0]["mask"] = rect(8, 0, 48, 40)
+    gts1, dts1 = gts[:1], dts[:1]
+    r = coco_segm_eval(gts1, dts1)
+    assert r["AP50"] == pytest.approx(1.0) and r["AP75"] == 0.0 and r["AP"] == pytest.approx(0.4)
+    # same boxes, different shapes: an L-shaped object against its bounding rectangle has mask IoU 0.75 < box IoU 1
+    L = rect(0, 0, 40, 40)
+    L[0:20, 20:40] = 0
+    r = coco_segm_eval([dict(image_id=1, category_id=1, mask=L)], [dict(image_id=1, category_id=1, mask=rect(0, 0, 40, 40), score=1.0)])
+    assert r["AP"] == pytest.approx(0.6)            # IoU 0.75: thresholds 0.50..0.75 (6 of 10)

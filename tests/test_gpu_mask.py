@@ -1,6 +1,7 @@
 """GPU parity tests for the Mask R-CNN specific pieces and a Mask R-CNN step."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import synth_boxes, synth_gt
 
@@ -110,3 +111,52 @@ def test_mask_rcnn_step(hip):
     assert hist[-1, 0] < hist[0, 0]          # ... and so does the RPN objectness loss
     g = m.arena.view(m.mask_head.convs[0].wi, "g")
     assert torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+def test_mask_paste_bit_exact(hip, oracle):
+    """Inference paste-back vs the C oracle: boxes inside, clipped by the frame, one pixel wide, empty, class -1."""
+    from mxdetection_amd.core import mask as M_
+    rng = np.random.default_rng(11)
+    R, S, Cpad, H, W = 9, 28, 88, 96, 132
+    logits = oracle.round_bf16((rng.standard_normal((R, S, S, Cpad)) * 3.0).astype(np.float32))
+    dets = np.zeros((R, 6), np.float32)
+    dets[0] = (10.2, 5.7, 80.4, 60.1, 0.9, 3)
+    dets[1] = (-20.0, -8.0, 40.0, 30.0, 0.8, 81)           # clipped by the frame top-left
+    dets[2] = (100.0, 70.0, 180.0, 140.0, 0.7, 1)          # clipped bottom-right
+    dets[3] = (50.0, 50.0, 50.0, 90.0, 0.6, 7)             # one pixel wide
+    dets[4] = (30.5, 40.5, 31.5, 41.5, 0.5, 12)            # half-way corners: round half to even
+    dets[5] = (60.0, 20.0, 40.0, 10.0, 0.4, 5)             # inverted box: nothing
+    dets[6] = (0.0, 0.0, 0.0, 0.0, 0.0, -1)                # padding row
+    dets[7] = (0.0, 0.0, 131.0, 95.0, 0.3, 80)             # whole frame
+    dets[8] = (5.0, 5.0, 8.0, 7.0, 0.2, 2)                 # smaller than the 28x28 map (down-scaling)
+    got = M_.mask_paste(torch.from_numpy(logits).cuda().to(torch.bfloat16), torch.from_numpy(dets).cuda(), H, W).cpu().numpy()
+    want = oracle.mask_paste(logits, dets, H, W)
+    assert np.array_equal(got, want)
+    assert not got[5].any() and not got[6].any() and got[0].any() and got[7].any()
+    # known answer: logits +8 on the left half of the map and -8 on the right -> the left half of the box is set
+    lg = np.full((1, S, S, 8), -8.0, np.float32)
+    lg[:, :, :S // 2, 0] = 8.0
+    d = np.array([[20, 10, 59, 49, 1.0, 1]], np.float32)
+    m = M_.mask_paste(torch.from_numpy(lg).cuda().to(torch.bfloat16), torch.from_numpy(d).cuda(), 64, 64).cpu().numpy()[0]
+    want = np.zeros((64, 64), np.uint8)
+    want[10:50, 20:40] = 1
+    assert np.array_equal(m, want)
+
+
+def test_mask_rcnn_predict_with_masks(hip):
+    from mxdetection_amd.models import FasterRCNN
+    model = FasterRCNN("cuda", depth=50, seed=7, with_mask=True, num_classes=81)
+    torch.manual_seed(0)
+    img = torch.randn((1, 3, 256, 320), device="cuda")
+    info = torch.tensor([[256.0, 320.0, 1.0]], device="cuda")
+    dets, num, masks = model.predict(img, info, score_thresh=0.0, max_per_image=20, with_masks=True)
+    torch.cuda.synchronize()
+    n = int(num[0])
+    assert masks.shape == (1, 20, 256, 320) and masks.dtype == torch.uint8 and n > 0
+    d = dets[0].cpu().numpy()
+    m = masks[0].cpu().numpy()
+    assert not m[n:].any()                                 # padding rows paste nothing
+    for k in range(n):                                      # every mask lives inside its (rounded) box
+        ys, xs = np.nonzero(m[k])
+        if ys.size:
+            assert xs.min() >= np.rint(d[k, 0]) and xs.max() <= np.rint(d[k, 2]) and ys.min() >= np.rint(d[k, 1]) and ys.max() <= np.rint(d[k, 3])
