@@ -110,6 +110,8 @@ typedef struct {
   int64_t cls_sn[8], cls_sy[8], cls_sx[8], cls_sa[8];
   int64_t reg_sn[8], reg_sy[8], reg_sx[8], reg_sc[8];
   int32_t dtype;            /* MXDET_DTYPE_F32 | MXDET_DTYPE_BF16 (both tensors) */
+  int32_t classes;          /* 0 or 1: plain. C > 1 (dense one-stage heads): A counts (anchor, class) pairs, a = anchor*C + c;
+                             * deltas and base anchors are looked up with a / C (base_anchors stays [A/C,4]) */
   const float* base_anchors[8]; /* device, [A,4] per level */
 } mxdet_pyramid_t;
 
@@ -394,6 +396,19 @@ int mxdet_subsample2_bwd(const uint16_t* dy, int32_t N, int32_t H, int32_t W, in
 /* adjoint of the nearest-neighbour 2x upsample: dcoarse[N,Hc,Wc,C] (+)= sum of the 2x2 fine cells */
 int mxdet_upsample2_bwd(const uint16_t* dfine, int32_t N, int32_t Hf, int32_t Wf, int32_t C,
                         int32_t accumulate, uint16_t* dcoarse, mxdet_stream_t stream);
+/* One-stage (RetinaNet) test-time detection, MXNet-lineage role: per level top-k of sigmoid scores over (anchor, class),
+ * decode, concatenate levels, per-class NMS, max_per_image -- a host loop in the lineage.
+ * p describes the head outputs with p->classes = C foreground classes and p->A = anchors_per_cell * C:
+ *   score(n,y,x,a*C+c) is the class logit, delta(n,y,x,a,k) the box delta (plain encoding, no normalisation).
+ * Per image and level the pre_nms_top_n largest logits (ties: lower (cell, anchor, class) index first) are decoded and
+ * clipped; the candidates of all levels are merged by (logit desc, index asc) and cut to 4096; score = sigmoid(logit);
+ * then exactly as mxdet_detection_postprocess: per class keep score > score_thresh, greedy NMS at nms_thresh, and the
+ * max_per_image best by (score desc, candidate rank asc, class asc). dets [N,max_per_image,6], class in 1..C. */
+size_t mxdet_retina_detect_workspace_bytes(const mxdet_pyramid_t* p, int32_t N, int32_t pre_nms_top_n);
+int mxdet_retina_detect(const mxdet_pyramid_t* p, int32_t N, const float* im_info, int32_t pre_nms_top_n,
+                        float score_thresh, float nms_thresh, int32_t max_per_image, float* dets, int32_t* num_dets,
+                        void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * process_data (README.md:23) -- the step in front of the path.
  * MXNet-lineage role: the host-side cv2 pipeline  flip -> cv2.resize(fx=fy=scale, INTER_LINEAR) -> BGR->RGB,

@@ -18,7 +18,7 @@ class PyramidT(C.Structure):
         ("cls", c_vp * 8), ("reg", c_vp * 8),
         ("cls_sn", c_i64 * 8), ("cls_sy", c_i64 * 8), ("cls_sx", c_i64 * 8), ("cls_sa", c_i64 * 8),
         ("reg_sn", c_i64 * 8), ("reg_sy", c_i64 * 8), ("reg_sx", c_i64 * 8), ("reg_sc", c_i64 * 8),
-        ("dtype", c_i32),
+        ("dtype", c_i32), ("classes", c_i32),
         ("base_anchors", c_vp * 8),
     ]
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "mxdet_nms_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_mask_paste_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "mxdet_mask_paste": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_retina_detect_workspace_bytes": (c_sz, [c_vp, c_i32, c_i32]),
+    "mxdet_retina_detect": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_f32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_image_preprocess": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mxdet_polygon_masks": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_detection_postprocess_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),

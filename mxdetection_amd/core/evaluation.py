@@ -279,3 +279,38 @@ def detections_to_coco(dets, num_dets, image_ids, scales, class_to_cat=None):
             cat = int(c) if class_to_cat is None else class_to_cat[int(c)]
             out.append({"image_id": image_ids[n], "category_id": cat, "bbox": [x1, y1, x2 - x1 + 1.0, y2 - y1 + 1.0], "score": s})
     return out
+
+
+class RetinaDetect:
+    """One-stage test-time detection on the device (mxdet_retina_detect): per-level top-k over (anchor, class) logits,
+    decode, merge, sigmoid, per-class NMS, max_per_image. cls[l] bf16/f32 [N,H,W,>=A*C] (channel a*C + c), reg[l]
+    [N,H,W,>=4A] (channel a*4 + k), base[l] device f32 [A,4]."""
+
+    def __init__(self, num_classes, strides, base_anchors, pre_nms_top_n=1000, score_thresh=0.05, nms_thresh=0.5,
+                 max_per_image=100):
+        self.C, self.strides, self.base = num_classes, list(strides), base_anchors
+        self.pre_n, self.score_thresh, self.nms_thresh, self.max_det = pre_nms_top_n, score_thresh, nms_thresh, max_per_image
+        self._ws = None
+
+    def __call__(self, cls, reg, im_info):
+        from .._lib import PyramidT
+        lib = _lib.load()
+        N = cls[0].shape[0]
+        A = self.base[0].shape[0]
+        d = PyramidT()
+        d.num_levels, d.A, d.classes = len(cls), A * self.C, self.C
+        d.dtype = _DT[cls[0].dtype]
+        for l, (c, r) in enumerate(zip(cls, reg)):
+            assert c.dtype == reg[l].dtype == cls[0].dtype and c.stride(3) == 1 and r.stride(3) == 1
+            d.H[l], d.W[l], d.stride[l] = c.shape[1], c.shape[2], self.strides[l]
+            d.cls[l], d.reg[l], d.base_anchors[l] = c.data_ptr(), r.data_ptr(), self.base[l].data_ptr()
+            d.cls_sn[l], d.cls_sy[l], d.cls_sx[l], d.cls_sa[l] = c.stride(0), c.stride(1), c.stride(2), 1
+            d.reg_sn[l], d.reg_sy[l], d.reg_sx[l], d.reg_sc[l] = r.stride(0), r.stride(1), r.stride(2), 1
+        need = lib.mxdet_retina_detect_workspace_bytes(C.byref(d), N, self.pre_n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=cls[0].device)
+        dets = torch.empty((N, self.max_det, 6), dtype=torch.float32, device=cls[0].device)
+        num = torch.empty((N,), dtype=torch.int32, device=cls[0].device)
+        check(lib.mxdet_retina_detect(C.byref(d), N, ptr(im_info), self.pre_n, self.score_thresh, self.nms_thresh, self.max_det,
+                                      ptr(dets), ptr(num), ptr(self._ws), self._ws.numel(), stream_ptr()), "retina_detect")
+        return dets, num

@@ -58,6 +58,7 @@ __global__ void det_score_box_kernel(const void* __restrict__ cls, const void* _
 // one workgroup per (foreground class, image): candidates above the threshold, sorted
 __global__ void __launch_bounds__(1024)
 det_class_sort_kernel(const float* __restrict__ scores, const float4* __restrict__ boxes,
+                      const int32_t* __restrict__ sparse_cls,   // null: dense [roi][class] inputs; else one class per roi
                       const int32_t* __restrict__ num_rois, int Rpi, int C, int Kpad, float thresh,
                       float4* __restrict__ sboxes, unsigned long long* __restrict__ skeys,
                       int32_t* __restrict__ counts) {
@@ -71,7 +72,9 @@ det_class_sort_kernel(const float* __restrict__ scores, const float4* __restrict
   int nr = num_rois[n];
   nr = nr > Rpi ? Rpi : (nr < 0 ? 0 : nr);
   for (int i = threadIdx.x; i < nr; i += blockDim.x) {
-    float s = scores[((size_t)n * Rpi + i) * C + c];
+    float s;
+    if (sparse_cls) s = sparse_cls[(size_t)n * Rpi + i] == c ? scores[(size_t)n * Rpi + i] : 0.0f;
+    else s = scores[((size_t)n * Rpi + i) * C + c];
     if (s > thresh) {
       int pos = atomicAdd(&n_sel, 1);
       list[pos] = ((unsigned long long)mxdet_float_key(s) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
@@ -86,7 +89,7 @@ det_class_sort_kernel(const float* __restrict__ scores, const float4* __restrict
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < cnt) {
       unsigned i = 0xffffffffu - (unsigned)(k & 0xffffffffull);
-      bx = boxes[((size_t)n * Rpi + i) * C + c];
+      bx = sparse_cls ? boxes[(size_t)n * Rpi + i] : boxes[((size_t)n * Rpi + i) * C + c];
     }
     sboxes[(size_t)b * Rpi + j] = bx;
   }
@@ -177,6 +180,57 @@ static DetWs det_carve(void* base, int N, int Rpi, int C) {
   return w;
 }
 
+// RetinaNet: merged per-level top-k (mxdet_proposal outputs) -> sparse candidates: probability, class, box
+__global__ void retina_candidates_kernel(const float* __restrict__ rois, const float* __restrict__ logit,
+                                         const int32_t* __restrict__ gidx, const int32_t* __restrict__ num, int N, int R,
+                                         int C, float* __restrict__ score, int32_t* __restrict__ cls,
+                                         float4* __restrict__ boxes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * R) return;
+  const int n = i / R, j = i - n * R;
+  if (j >= num[n]) {
+    score[i] = 0.0f; cls[i] = 0; boxes[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float z = logit[i];
+  score[i] = z >= 0.0f ? 1.0f / (1.0f + mxdet_expf(-z)) : mxdet_expf(z) / (1.0f + mxdet_expf(z));
+  cls[i] = gidx[i] % C + 1;               // level offsets are multiples of A*C
+  const float* r = rois + (size_t)i * 5;
+  boxes[i] = make_float4(r[1], r[2], r[3], r[4]);
+}
+
+struct RetinaWs {
+  float* rois; float* logit; int32_t* gidx; int32_t* num; float* score; int32_t* cls; float4* boxes;
+  float4* sboxes; unsigned long long* skeys; int32_t* counts; int32_t* keep_idx; int32_t* num_keep;
+  void* nms_ws; size_t nms_bytes; void* prop_ws; size_t prop_bytes; size_t total;
+};
+
+static RetinaWs retina_carve(void* base, const mxdet_pyramid_t* p, int N, int pre_n, int R, int C) {
+  RetinaWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  char* q = (char*)base;
+  const size_t NR = (size_t)N * R, B = (size_t)N * C;
+  w.rois = (float*)(q + take(NR * 20));
+  w.logit = (float*)(q + take(NR * 4));
+  w.gidx = (int32_t*)(q + take(NR * 4));
+  w.num = (int32_t*)(q + take((size_t)N * 4));
+  w.score = (float*)(q + take(NR * 4));
+  w.cls = (int32_t*)(q + take(NR * 4));
+  w.boxes = (float4*)(q + take(NR * 16));
+  w.sboxes = (float4*)(q + take(B * R * 16));
+  w.skeys = (unsigned long long*)(q + take(B * R * 8));
+  w.counts = (int32_t*)(q + take(B * 4));
+  w.keep_idx = (int32_t*)(q + take(B * R * 4));
+  w.num_keep = (int32_t*)(q + take(B * 4));
+  w.nms_bytes = mxdet_nms_batched_workspace_bytes((int32_t)B, R);
+  w.nms_ws = (void*)(q + take(w.nms_bytes));
+  w.prop_bytes = mxdet_proposal_workspace_bytes(p, N, pre_n);
+  w.prop_ws = (void*)(q + take(w.prop_bytes));
+  w.total = off;
+  return w;
+}
+
 }  // namespace mxdet
 
 using namespace mxdet;
@@ -219,7 +273,8 @@ extern "C" int mxdet_detection_postprocess(const void* cls_logits, const void* b
   int Kpad = 1;
   while (Kpad < Rpi) Kpad <<= 1;
   hipLaunchKernelGGL(det_class_sort_kernel, dim3(C - 1, N), dim3(1024), 0, s, (const float*)w.scores,
-                     (const float4*)w.boxes, num_rois, Rpi, C, Kpad, score_thresh, w.sboxes, w.skeys, w.counts);
+                     (const float4*)w.boxes, (const int32_t*)nullptr, num_rois, Rpi, C, Kpad, score_thresh, w.sboxes, w.skeys,
+                     w.counts);
   int rc = check_launch("detection_postprocess(score/sort)");
   if (rc) return rc;
   rc = mxdet_nms_batched((const float*)w.sboxes, w.counts, nullptr, B, Rpi, nms_thresh, max_per_image, w.keep_idx,
@@ -229,4 +284,49 @@ extern "C" int mxdet_detection_postprocess(const void* cls_logits, const void* b
                      (const unsigned long long*)w.skeys, (const float4*)w.sboxes, (const int32_t*)w.keep_idx,
                      (const int32_t*)w.num_keep, dets, num_dets);
   return check_launch("detection_postprocess(merge)");
+}
+
+static int retina_candidates_cap(const mxdet_pyramid_t* p, int pre_n) {
+  long long r = (long long)p->num_levels * pre_n;
+  return (int)(r < kDetMaxRois ? r : kDetMaxRois);
+}
+
+extern "C" size_t mxdet_retina_detect_workspace_bytes(const mxdet_pyramid_t* p, int32_t N, int32_t pre_nms_top_n) {
+  if (!p || N <= 0 || pre_nms_top_n <= 0 || p->num_levels <= 0 || p->classes <= 0) return 0;
+  return retina_carve(nullptr, p, N, pre_nms_top_n, retina_candidates_cap(p, pre_nms_top_n), p->classes).total;
+}
+
+extern "C" int mxdet_retina_detect(const mxdet_pyramid_t* p, int32_t N, const float* im_info, int32_t pre_nms_top_n,
+                                   float score_thresh, float nms_thresh, int32_t max_per_image, float* dets,
+                                   int32_t* num_dets, void* workspace, size_t workspace_bytes, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(p && im_info && dets && num_dets, MXDET_EINVAL, "retina_detect: null pointer");
+  MXDET_REQUIRE(N > 0 && p->num_levels > 0 && p->classes >= 1 && pre_nms_top_n > 0, MXDET_ESHAPE, "retina_detect: bad sizes");
+  const int C = p->classes, R = retina_candidates_cap(p, pre_nms_top_n), B = N * C;
+  MXDET_REQUIRE(max_per_image > 0 && max_per_image <= R, MXDET_ESHAPE, "retina_detect: bad max_per_image %d", max_per_image);
+  const size_t merge_lds = (size_t)C * max_per_image * 8 + (size_t)C * 4;
+  MXDET_REQUIRE(merge_lds <= 150 * 1024, MXDET_ESHAPE, "retina_detect: classes*max_per_image too large");
+  RetinaWs w = retina_carve(workspace, p, N, pre_nms_top_n, R, C);
+  MXDET_REQUIRE(workspace && workspace_bytes >= w.total, MXDET_EWORKSPACE, "retina_detect: workspace %zu < %zu",
+                workspace_bytes, w.total);
+  // per-level top-k + decode + merge: the proposal path with suppression switched off (no IoU exceeds 2)
+  int rc = mxdet_proposal(p, N, im_info, pre_nms_top_n, R, 2.0f, 0.0f, w.rois, w.logit, w.gidx, w.num, w.prop_ws,
+                          w.prop_bytes, stream);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(retina_candidates_kernel, dim3(ceil_div(N * R, 256)), dim3(256), 0, s, (const float*)w.rois,
+                     (const float*)w.logit, (const int32_t*)w.gidx, (const int32_t*)w.num, N, R, C, w.score, w.cls, w.boxes);
+  int Kpad = 1;
+  while (Kpad < R) Kpad <<= 1;
+  hipLaunchKernelGGL(det_class_sort_kernel, dim3(C, N), dim3(1024), 0, s, (const float*)w.score, (const float4*)w.boxes,
+                     (const int32_t*)w.cls, (const int32_t*)w.num, R, C + 1, Kpad, score_thresh, w.sboxes, w.skeys, w.counts);
+  rc = check_launch("retina_detect(candidates/sort)");
+  if (rc) return rc;
+  rc = mxdet_nms_batched((const float*)w.sboxes, w.counts, nullptr, B, R, nms_thresh, max_per_image, w.keep_idx,
+                         w.num_keep, w.nms_ws, w.nms_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(det_merge_kernel, dim3(N), dim3(1024), merge_lds, s, C + 1, R, max_per_image, max_per_image,
+                     (const unsigned long long*)w.skeys, (const float4*)w.sboxes, (const int32_t*)w.keep_idx,
+                     (const int32_t*)w.num_keep, dets, num_dets);
+  return check_launch("retina_detect(merge)");
 }

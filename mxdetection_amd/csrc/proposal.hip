@@ -23,6 +23,7 @@ struct PyramidDev {
   long long reg_sn[8], reg_sy[8], reg_sx[8], reg_sc[8];
   const float* base[8];
   long long level_offset[8];  // global anchor index of the level's first anchor
+  int classes;                // >= 1: (anchor, class) pairs share the anchor's deltas and base box
 };
 
 __device__ __forceinline__ float pyr_score(const PyramidDev& p, int l, int n, int local) {
@@ -231,6 +232,7 @@ __global__ void proposal_decode_kernel(PyramidDev p, int N, int pre_n, const flo
   int a = local % A;
   int cell = local / A;
   int x = cell % p.W[l], y = cell / p.W[l];
+  a /= p.classes;
   const float* base = p.base[l] + a * 4;
   float sx = (float)(x * p.stride[l]), sy = (float)(y * p.stride[l]);
   float ax1 = base[0] + sx, ay1 = base[1] + sy, ax2 = base[2] + sx, ay2 = base[3] + sy;
@@ -394,6 +396,8 @@ extern "C" int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* 
   PyramidDev d;
   memset(&d, 0, sizeof(d));
   d.num_levels = L; d.A = p->A; d.dtype = p->dtype;
+  d.classes = p->classes > 1 ? p->classes : 1;
+  MXDET_REQUIRE(p->A % d.classes == 0, MXDET_ESHAPE, "proposal: A=%d is not a multiple of classes=%d", p->A, d.classes);
   long long off = 0;
   for (int l = 0; l < L; ++l) {
     MXDET_REQUIRE(p->H[l] > 0 && p->W[l] > 0 && p->stride[l] > 0 && p->cls[l] && p->reg[l] &&

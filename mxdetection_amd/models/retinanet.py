@@ -39,6 +39,22 @@ class RetinaNet(DetectorBase):
         self.dC = [None] + [torch.empty(s, dtype=torch.bfloat16, device=dev) for s in c_shapes[1:]]
         self.planned = key
 
+    def predict(self, image, im_info, score_thresh=0.05, nms_thresh=0.5, max_per_image=100, pre_nms_top_n=1000):
+        """Inference: forward, then per-level top-k / decode / per-class NMS / top-k on the GPU (core/evaluation
+        RetinaDetect). Returns (dets [N,max_per_image,6] = x1,y1,x2,y2,score,class in 1..C; num_dets [N])."""
+        from ..core.evaluation import RetinaDetect
+        N, _, H, W = image.shape
+        g_max = self.planned[3] if self.planned is not None and self.planned[:3] == (N, H, W) else 100
+        self.plan(N, H, W, g_max)
+        P = self.neck.forward(self.backbone.forward(image)[1:])
+        co, bo = self.head.forward(P)
+        key = (score_thresh, nms_thresh, max_per_image, pre_nms_top_n)
+        if getattr(self, "_det_key", None) != key:
+            self._det = RetinaDetect(self.head.Cn, self.strides, self.head.base, pre_nms_top_n, score_thresh, nms_thresh,
+                                     max_per_image)
+            self._det_key = key
+        return self._det(co, bo, im_info)
+
     def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0, step_dev=None, gt_masks=None):
         N, _, H, W = image.shape
         self.plan(N, H, W, gt_boxes.shape[1])

@@ -974,3 +974,43 @@ API void oracle_mask_paste(const float* logits, const float* dets, int R, int S,
   }
   free(p);
 }
+
+/* One-stage test-time detection, second half (see include/mxdet.h mxdet_retina_detect): sparse candidates -- one class
+ * per candidate, cls 0 = none -- through per-class threshold / sort / greedy NMS and the per-image cut. */
+API float oracle_sigmoid(float z) { return o_sigmoid(z); }
+API void oracle_class_nms_topk(const float* boxes, const float* scores, const int32_t* cls, const int32_t* num, int N,
+                               int R, int C, float score_thresh, float nms_thresh, int max_det, float* dets,
+                               int32_t* num_dets) {
+  o_det* cand = (o_det*)malloc(sizeof(o_det) * (size_t)(R > 0 ? R : 1));
+  o_det* kept = (o_det*)malloc(sizeof(o_det) * (size_t)(R > 0 ? R : 1) * (size_t)(C > 0 ? C : 1));
+  float* bx = (float*)malloc(sizeof(float) * 4 * (size_t)(R > 0 ? R : 1));
+  int32_t* keep = (int32_t*)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+  for (int n = 0; n < N; ++n) {
+    int nr = num[n]; nr = nr > R ? R : (nr < 0 ? 0 : nr);
+    int nkept = 0;
+    for (int c = 1; c <= C; ++c) {
+      int nc = 0;
+      for (int i = 0; i < nr; ++i) {
+        const size_t r = (size_t)n * R + i;
+        if (cls[r] == c && scores[r] > score_thresh) {
+          cand[nc].key = o_float_key(scores[r]); cand[nc].roi = (uint32_t)i; cand[nc].cls = (uint32_t)c; cand[nc].score = scores[r];
+          memcpy(cand[nc].box, boxes + r * 4, 16);
+          ++nc;
+        }
+      }
+      qsort(cand, (size_t)nc, sizeof(o_det), o_cmp_det_cls);
+      for (int j = 0; j < nc; ++j) memcpy(bx + 4 * j, cand[j].box, 16);
+      int nk = oracle_nms(bx, nc, NULL, nms_thresh, max_det, keep);
+      for (int j = 0; j < nk; ++j) kept[nkept++] = cand[keep[j]];
+    }
+    qsort(kept, (size_t)nkept, sizeof(o_det), o_cmp_det_all);
+    int nout = nkept < max_det ? nkept : max_det;
+    for (int j = 0; j < max_det; ++j) {
+      float* d = dets + ((size_t)n * max_det + j) * 6;
+      if (j < nout) { memcpy(d, kept[j].box, 16); d[4] = kept[j].score; d[5] = (float)kept[j].cls; }
+      else { d[0] = d[1] = d[2] = d[3] = d[4] = 0.0f; d[5] = -1.0f; }
+    }
+    num_dets[n] = nout;
+  }
+  free(cand); free(kept); free(bx); free(keep);
+}

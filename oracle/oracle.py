@@ -393,3 +393,32 @@ def mask_paste(logits, dets, H, W, thresh=0.5):
     lib().oracle_mask_paste(_vp(logits), _vp(dets), C.c_int(R), C.c_int(S), C.c_int(Cpad), C.c_int(H), C.c_int(W),
                             C.c_float(thresh), _vp(masks))
     return masks
+
+
+def class_nms_topk(boxes, scores, cls, num, C_, score_thresh, nms_thresh, max_det):
+    boxes, scores, cls = _c(boxes, np.float32), _c(scores, np.float32), _c(cls, np.int32)
+    N, R = scores.shape
+    dets = np.zeros((N, max_det, 6), np.float32)
+    nd = np.zeros((N,), np.int32)
+    lib().oracle_class_nms_topk(_vp(boxes), _vp(scores), _vp(cls), _vp(_c(num, np.int32)), C.c_int(N), C.c_int(R), C.c_int(C_),
+                                C.c_float(score_thresh), C.c_float(nms_thresh), C.c_int(max_det), _vp(dets), _vp(nd))
+    return dets, nd
+
+
+def retina_detect(cls_logits, deltas, base, H, W, strides, im_info, num_classes, pre_n=1000, score_thresh=0.05, nms_thresh=0.5,
+                  max_det=100, cap=4096):
+    """cls_logits[l]: [N, H*W*A*C] f32 ((y,x,a,c) order); deltas[l]: [N, H*W*A, 4]; base[l]: [A,4]. Restates
+    mxdet_retina_detect: per-level top-k over (anchor, class) -> decode -> merge (cut to `cap`) -> sigmoid -> per-class NMS."""
+    Cn = num_classes
+    exp_d = [np.repeat(_c(d, np.float32), Cn, axis=1) for d in deltas]
+    exp_b = [np.repeat(_c(b, np.float32), Cn, axis=0) for b in base]
+    L = len(cls_logits)
+    post = min(L * pre_n, cap)
+    rois, logit, gidx, num = proposal(cls_logits, exp_d, exp_b, H, W, strides, im_info, pre_n, post, 2.0, 0.0)
+    lib().oracle_sigmoid.restype = C.c_float
+    lib().oracle_sigmoid.argtypes = [C.c_float]
+    prob = np.array([[lib().oracle_sigmoid(float(z)) for z in row] for row in logit], np.float32)
+    cls = (gidx % Cn + 1).astype(np.int32)
+    for n in range(rois.shape[0]):
+        cls[n, num[n]:] = 0
+    return class_nms_topk(rois[:, :, 1:5], prob, cls, num, Cn, score_thresh, nms_thresh, max_det)

@@ -87,3 +87,57 @@ def test_retinanet_train_step(hip):
     assert hist[0, 0] > 0 and hist[0, 1] > 0
     assert hist[-1].sum() < hist[0].sum(), hist
     assert 9 * (32 * 40 + 16 * 20 + 8 * 10 + 4 * 5 + 2 * 3) == m.head.anchors.shape[0]
+
+
+def test_retina_detect_bit_exact(hip, oracle):
+    """mxdet_retina_detect vs the oracle restatement: 3 levels, 3 anchors x 5 classes, bf16-valued logits (heavy ties),
+    padded channel dimensions as the head produces them."""
+    import torch
+    from mxdetection_amd.core.evaluation import RetinaDetect
+    rng = np.random.default_rng(21)
+    N, A, Cn = 2, 3, 5
+    shapes, strides = [(16, 20), (8, 10), (4, 5)], [8, 16, 32]
+    ld_cls, ld_reg = 64, 64
+    base = [oracle.base_anchors(s) for s in strides]
+    cls, reg, cls_o, reg_o = [], [], [], []
+    for (H, W) in shapes:
+        c = oracle.round_bf16((rng.standard_normal((N, H, W, ld_cls)) * 2.0 - 1.0).astype(np.float32))
+        r = oracle.round_bf16((rng.standard_normal((N, H, W, ld_reg)) * 0.3).astype(np.float32))
+        cls.append(torch.from_numpy(c).cuda().to(torch.bfloat16))
+        reg.append(torch.from_numpy(r).cuda().to(torch.bfloat16))
+        cls_o.append(c[..., :A * Cn].reshape(N, -1))
+        reg_o.append(r[..., :A * 4].reshape(N, H * W * A, 4))
+    info = np.array([[128, 160, 1.0], [120, 150, 1.0]], np.float32)
+    det = RetinaDetect(Cn, strides, [torch.from_numpy(b).cuda() for b in base], pre_nms_top_n=60, score_thresh=0.05,
+                       nms_thresh=0.5, max_per_image=30)
+    dets, num = det(cls, reg, torch.from_numpy(info).cuda())
+    want, wnum = oracle.retina_detect(cls_o, reg_o, base, [s[0] for s in shapes], [s[1] for s in shapes], strides, info, Cn,
+                                      pre_n=60, score_thresh=0.05, nms_thresh=0.5, max_det=30)
+    assert np.array_equal(num.cpu().numpy(), wnum)
+    assert np.array_equal(dets.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    d = dets.cpu().numpy()
+    for n in range(N):
+        k = int(wnum[n])
+        assert k == 30 and np.all(np.diff(d[n, :k, 4]) <= 0) and np.all((d[n, :k, 5] >= 1) & (d[n, :k, 5] <= Cn))
+        assert np.all(d[n, :k, 2] <= info[n, 1] - 1) and np.all(d[n, :k, 0] >= 0) and np.all(d[n, k:, 5] == -1)
+    # per class, no two kept boxes overlap by more than the NMS threshold
+    for c in range(1, Cn + 1):
+        b = d[0, :30][d[0, :30, 5] == c][:, :4]
+        if len(b) > 1:
+            iou = oracle.box_iou(b, b)
+            assert np.all(iou[np.triu_indices(len(b), 1)] <= 0.5)
+
+
+def test_retinanet_predict(hip):
+    import torch
+    from mxdetection_amd.models import RetinaNet
+    model = RetinaNet("cuda", depth=50 if False else 101, num_classes=80, seed=3)
+    torch.manual_seed(0)
+    img = torch.randn((1, 3, 256, 320), device="cuda")
+    info = torch.tensor([[256.0, 320.0, 1.0]], device="cuda")
+    dets, num = model.predict(img, info, score_thresh=0.0, max_per_image=50)
+    torch.cuda.synchronize()
+    n = int(num[0])
+    d = dets[0].cpu().numpy()
+    assert 0 < n <= 50 and np.all(np.diff(d[:n, 4]) <= 0) and np.all(d[:n, 4] < 0.05)     # focal prior: p starts near 0.01
+    assert np.all((d[:n, 5] >= 1) & (d[:n, 5] <= 80)) and np.all(d[:n, 2] <= 319) and np.all(d[:n, 3] <= 255)

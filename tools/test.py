@@ -22,7 +22,6 @@ def main():
     from mxdetection_amd.models.builder import build_detector, build_loader
     from mxdetection_amd.utils import load_config
     cfg = load_config(args.cfg, list(args.overrides) + ["TRAIN.flip=false"])
-    assert cfg.network.type in ("faster_rcnn", "mask_rcnn"), "box evaluation is wired for the two-stage models"
     model = build_detector(cfg)
     if args.params:
         model.load_checkpoint(args.params, strict=False)
