@@ -434,6 +434,7 @@ typedef struct {
   double inv_scale;       /* 1 / scale */
 } mxdet_image_desc_t;
 #define MXDET_PREPROCESS_MAX_BATCH 64
+int mxdet_debug_preprocess_direct(int32_t on);   /* test hook: 1 = always use the direct-gather kernel (wide-frame path) */
 int mxdet_image_preprocess(const mxdet_image_desc_t* images /* host array */, int32_t N, int32_t Hp, int32_t Wp,
                            const float* mean3 /* host */, const float* std3 /* host */, int32_t swap_rb,
                            uint16_t* out, mxdet_stream_t stream);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mxdet_mask_paste": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_retina_detect_workspace_bytes": (c_sz, [c_vp, c_i32, c_i32]),
     "mxdet_retina_detect": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_f32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_debug_preprocess_direct": (c_i32, [c_i32]),
     "mxdet_image_preprocess": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mxdet_polygon_masks": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_detection_postprocess_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),

@@ -68,6 +68,67 @@ image_preprocess_kernel(PreTab tab, PreNorm nm, int N, int Hp, int Wp, int swap_
   for (int c = 0; c < 3; ++c) *(uint4*)(o + c * plane) = make_uint4(pk[c][0], pk[c][1], pk[c][2], pk[c][3]);
 }
 
+// Row-staged form (the one launched when both source rows fit in LDS): one workgroup = one output row. The two source
+// rows the row blends are copied to LDS with aligned 4-byte loads (the byte-granular global gathers of the direct form
+// -- 96 one-byte loads per lane -- were what bounded it, not HBM), the taps are then LDS byte reads.
+__global__ void __launch_bounds__(256)
+image_preprocess_rows_kernel(PreTab tab, PreNorm nm, int N, int Hp, int Wp, int swap_rb, uint16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rows_lds[];
+  const int y = blockIdx.x % Hp, n = blockIdx.x / Hp;
+  const mxdet_image_desc_t& d = tab.im[n];
+  const long long plane = (long long)Hp * Wp;
+  uint16_t* orow = out + ((long long)n * 3 * Hp + y) * Wp;
+  const int wch = Wp >> 3;
+  if (y >= d.dst_h) {
+    for (int i = threadIdx.x; i < 3 * wch; i += 256) {
+      const int c = i / wch, xc = i - c * wch;
+      *(uint4*)(orow + c * plane + xc * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
+  int sy0, sy1, b0, b1;
+  resize_coef(y, d.inv_scale, d.src_h, sy0, sy1, b0, b1);
+  const int rb = d.src_w * 3;                       // bytes per source row
+  const int pitch = (rb + 3 + 3) & ~3;              // staged bytes per row: lead (<= 3) + row, rounded to dwords
+  int lead[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint8_t* row = d.src + (long long)(r ? sy1 : sy0) * rb;
+    lead[r] = (int)((uintptr_t)row & 3);
+    const uint32_t* arow = (const uint32_t*)(row - lead[r]);
+    const int nd = (lead[r] + rb + 3) >> 2;
+    uint32_t* dst = (uint32_t*)(rows_lds + r * pitch);
+    for (int i = threadIdx.x; i < nd; i += 256) dst[i] = arow[i];
+  }
+  __syncthreads();
+  const uint8_t* r0 = rows_lds + lead[0];
+  const uint8_t* r1 = rows_lds + pitch + lead[1];
+  for (int xc = threadIdx.x; xc < wch; xc += 256) {
+    unsigned pk[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (xc * 8 < d.dst_w) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int x = xc * 8 + j;
+        if (x >= d.dst_w) continue;
+        int sx0, sx1, a0, a1;
+        resize_coef(x, d.inv_scale, d.src_w, sx0, sx1, a0, a1);
+        if (d.flip) { sx0 = d.src_w - 1 - sx0; sx1 = d.src_w - 1 - sx1; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int sc = swap_rb ? 2 - c : c;
+          const int t0 = (int)r0[sx0 * 3 + sc] * a0 + (int)r0[sx1 * 3 + sc] * a1;
+          const int t1 = (int)r1[sx0 * 3 + sc] * a0 + (int)r1[sx1 * 3 + sc] * a1;
+          const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+          const float f = __fdiv_rn(__fsub_rn((float)v, nm.mean[c]), nm.stdv[c]);
+          pk[c][j >> 1] |= (unsigned)f32_to_bf16_bits(f) << (16 * (j & 1));
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *(uint4*)(orow + c * plane + xc * 8) = make_uint4(pk[c][0], pk[c][1], pk[c][2], pk[c][3]);
+  }
+}
+
 // One lane = 4 consecutive pixels of one row of one instance mask (one 32-bit store). The row test of an edge is
 // uniform over the workgroup's row, so rows that no edge straddles cost two compares per edge and no division.
 __global__ void __launch_bounds__(256)
@@ -105,6 +166,12 @@ polygon_masks_kernel(const float2* __restrict__ verts, const int* __restrict__ p
 
 using namespace mxdet;
 
+static int g_preprocess_direct = 0;   // test hook (mxdet_debug_preprocess_direct): force the direct-gather form
+extern "C" int mxdet_debug_preprocess_direct(int32_t on) {
+  g_preprocess_direct = on;
+  return MXDET_OK;
+}
+
 extern "C" int mxdet_image_preprocess(const mxdet_image_desc_t* images, int32_t N, int32_t Hp, int32_t Wp,
                                       const float* mean3, const float* std3, int32_t swap_rb, uint16_t* out,
                                       mxdet_stream_t stream) {
@@ -132,9 +199,17 @@ extern "C" int mxdet_image_preprocess(const mxdet_image_desc_t* images, int32_t 
     nm.mean[c] = mean3[c];
     nm.stdv[c] = std3[c];
   }
-  const long long items = (long long)N * Hp * (Wp / 8);
-  hipLaunchKernelGGL(image_preprocess_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), tab,
-                     nm, N, Hp, Wp, swap_rb, out);
+  int max_w = 0;
+  for (int n = 0; n < N; ++n) max_w = max_w > images[n].src_w ? max_w : images[n].src_w;
+  const size_t lds = 2 * (size_t)((max_w * 3 + 6) & ~3);
+  if (lds <= 60 * 1024 && !g_preprocess_direct) {
+    hipLaunchKernelGGL(image_preprocess_rows_kernel, dim3((unsigned)(N * Hp)), dim3(256), lds, as_stream(stream), tab, nm, N,
+                       Hp, Wp, swap_rb, out);
+  } else {      // very wide frames: direct global gathers
+    const long long items = (long long)N * Hp * (Wp / 8);
+    hipLaunchKernelGGL(image_preprocess_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), tab,
+                       nm, N, Hp, Wp, swap_rb, out);
+  }
   return check_launch("image_preprocess");
 }
 

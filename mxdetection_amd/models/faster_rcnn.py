@@ -114,6 +114,9 @@ class FasterRCNN(DetectorBase):
         d_pooled = self.bbox_head.backward()
         if self.roi_bwd_gather:
             self._join_branch()                                       # dP[l] holds the RPN part
+            # the head bucket's weight gradients, update and filter transposes go to the side stream FIRST: they are
+            # MFMA / HBM bound and run underneath the gather, which is latency-bound (dependent loads, ~200 us)
+            self._reduce(0, self.mark_rpn)
             self.roi_extractor.backward_gather(d_pooled.view(pooled.shape), self.dP[:4], accumulate=True)
             if self.with_mask:
                 self.mask_roi_extractor.backward_gather(d_mpooled, self.dP[:4], accumulate=True)
@@ -123,7 +126,7 @@ class FasterRCNN(DetectorBase):
                 self.mask_roi_extractor.backward(d_mpooled, self.dP[:4], shared_acc=acc, zero=False, finalize=False)
             self._join_branch()
             self.roi_extractor.finalize(self.dP[:4], accumulate=True)     # dP[l] = RPN part + RoI part
-        self._reduce(0, self.mark_rpn)
+            self._reduce(0, self.mark_rpn)
         self.neck.backward(self.dP, self.dC, [False, True, True, True])
         self._reduce(self.mark_rpn, self.mark_fpn)
         lo = self.mark_fpn

@@ -49,6 +49,22 @@ def test_preprocess_coco_sizes_vs_oracle(hip, oracle, swap):
         assert not o[n, :, dh:, :].any() and not o[n, :, :, dw:].any() and o[n, :, :dh, :dw].any()
 
 
+def test_preprocess_direct_gather_form(hip, oracle):
+    """The wide-frame fallback (no LDS row staging) gives the same bits."""
+    rng = np.random.default_rng(9)
+    ims = [rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), rng.integers(0, 256, (50, 41, 3), dtype=np.uint8)]
+    pre = T.BatchPreprocessor(target_size=96, max_size=160, means=MEAN, stds=STD, swap_rb=True, pad_to=(160, 160))
+    frames = [torch.from_numpy(i).cuda() for i in ims]
+    a, _, scales = pre(frames, [True, False])
+    hip.load().mxdet_debug_preprocess_direct(1)
+    try:
+        b, _, _ = pre(frames, [True, False])
+    finally:
+        hip.load().mxdet_debug_preprocess_direct(0)
+    want = oracle.image_preprocess(ims, scales, [True, False], 160, 160, MEAN, STD, swap_rb=True)
+    assert np.array_equal(_bits(a), want) and np.array_equal(_bits(b), want)
+
+
 def test_preprocess_downscale_and_single_pixel(hip, oracle):
     rng = np.random.default_rng(6)
     ims = [rng.integers(0, 256, (1500, 2100, 3), dtype=np.uint8), rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)]
