@@ -156,3 +156,38 @@ def test_checkpoint_round_trip(hip, tmp_path):
     lb = torch.cat(b.forward_backward(image, gt, im_info, step=1)).clone()
     torch.cuda.synchronize()
     assert torch.equal(la, lb)
+
+
+@pytest.mark.parametrize("kind", ["faster_rcnn", "mask_rcnn", "retinanet"])
+def test_step_with_an_image_without_ground_truth(hip, kind):
+    """One image of the batch carries no object (all GT rows padding): targets are all background, losses and
+    gradients stay finite, and the box-regression terms only see the other image."""
+    import torch
+    from mxdetection_amd.models import FasterRCNN, RetinaNet
+    N, H, W = 2, 256, 320
+    image, gt, im_info = _inputs(N, H, W, seed=4)
+    gt[1, :, :] = -1.0
+    if kind == "retinanet":
+        m = RetinaNet("cuda", depth=101, seed=7)
+        masks = None
+    else:
+        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000, with_mask=(kind == "mask_rcnn"))
+        masks = torch.zeros((N, 16, H, W), dtype=torch.uint8, device="cuda") if kind == "mask_rcnn" else None
+        if masks is not None:
+            b = gt[0].cpu().numpy()
+            for g in range(16):
+                if b[g, 4] >= 0:
+                    masks[0, g, int(b[g, 1]):int(b[g, 3]) + 1, int(b[g, 0]):int(b[g, 2]) + 1] = 1
+    losses = m.forward_backward(image, gt, im_info, step=1, image_offset=0, gt_masks=masks)
+    torch.cuda.synchronize()
+    vals = torch.cat(list(losses)).cpu().numpy()
+    assert np.all(np.isfinite(vals)) and np.all(vals >= 0), vals
+    assert torch.isfinite(m.arena.g).all() and m.arena.g.abs().sum().item() > 0
+    # an entirely empty batch is legal too
+    gt[:] = -1.0
+    losses = m.forward_backward(image, gt, im_info, step=2, image_offset=0,
+                                gt_masks=torch.zeros_like(masks) if masks is not None else None)
+    torch.cuda.synchronize()
+    vals = torch.cat(list(losses)).cpu().numpy()
+    assert np.all(np.isfinite(vals)), vals
+    assert torch.isfinite(m.arena.g).all()
