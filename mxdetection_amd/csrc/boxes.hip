@@ -157,67 +157,98 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, const int32_t* __re
 }
 
 // Stage 2 for lists of at most NW*64 boxes (the RPN case: 2000 -> 32 words). Same algorithm as nms_scan_kernel with
-// the global-memory latency taken off the dependent chain: every lane keeps its own box's mask row (words w..nw-1) in
-// registers, and the rows of word w+1 are fetched -- all loads independent, issued back to back -- while word w is
-// being resolved. The OR of a kept box's row into the later `removed` words then reads registers only.
+// the global-memory latency taken off the dependent chain and without atomics:
+//   * the mask rows of the 64 boxes of word w sit in LDS ([box][word], padded pitch), those of word w+1 are fetched --
+//     all loads independent, issued back to back -- while word w is being resolved;
+//   * lane L owns word L of the `removed` set in a register. After the 64-step resolve of word w, the kept boxes' rows
+//     are OR-ed in by a wave-uniform loop over the kept bits: every lane reads ITS word of row i (consecutive lanes,
+//     consecutive LDS words: conflict-free). The earlier form had each kept lane OR its row into shared words with
+//     same-address LDS atomics -- up to 64 serialised operations per word, most of the kernel's 240 us.
 template <int NW>
 __global__ void __launch_bounds__(64)
 nms_scan_rows_kernel(const unsigned long long* __restrict__ mask, const int32_t* __restrict__ counts,
                      const uint8_t* __restrict__ invalid, int n_max, int nwords_max, int max_keep,
                      int32_t* __restrict__ keep_idx, int32_t* __restrict__ num_keep) {
-  __shared__ unsigned long long rem[NW];
+  __shared__ unsigned long long rows[2][64][NW + 1];
   const int b = blockIdx.x, lane = threadIdx.x;
   int n = counts[b];
   n = n > n_max ? n_max : n;
   n = __builtin_amdgcn_readfirstlane(n);
   const int nw = (n + 63) >> 6;
-  const unsigned long long* m = mask + (int64_t)b * n_max * nwords_max;
+  const unsigned long long* m = mask + (int64_t)b * n_max * NW;   // pitch NW (nwords_max <= NW columns are in use)
+  unsigned long long myrem = 0ull;               // lane L: word L of the removed set
   for (int w = 0; w < nw; ++w) {
     int idx = w * 64 + lane;
     bool bad = (idx >= n) || (invalid != nullptr && invalid[(int64_t)b * n_max + idx] != 0);
     unsigned long long bm = __ballot(bad);
-    if (lane == 0) rem[w] = bm;
+    if (lane == w) myrem = bm;
   }
-  __syncthreads();
-  unsigned long long cur[NW], nxt[NW];
-  auto load_row = [&](unsigned long long (&r)[NW], int w) {   // words w..nw-1 of box w*64+lane (upper triangle only)
-    const int row = w * 64 + lane;
-    const unsigned long long* rp = m + (int64_t)row * nwords_max;
+  // The mask pitch is NW words for this kernel (mxdet_nms_batched pads it), so the 64 rows of word w are one
+  // contiguous run of 64*NW words: lane l fetches words l, l+64, ... of the run -- 512 contiguous bytes per wave
+  // instruction at immediate offsets, no per-load address or predicate arithmetic (one row per lane made every
+  // instruction touch 64 separate cache lines; predicated triangle loads cost ~35 instructions each). Entries the mask
+  // kernel never wrote (lower triangle, words past the list, rows past n -- the buffer has 64 rows of slack) are
+  // read but never used: rows of boxes >= n are never kept, lanes outside (w, nw) drop what they OR.
+  unsigned long long nxt[NW];
+  auto load_row = [&](unsigned long long (&r)[NW], int w) {
+    const unsigned long long* bp = m + (int64_t)(w * 64) * NW + lane;
 #pragma unroll
-#ifdef NMS_ABL_NOLOAD
-    for (int j = 0; j < NW; ++j) r[j] = (j == w && row < n) ? rp[j] : 0ull;
-#else
-    for (int j = 0; j < NW; ++j) r[j] = (j >= w && j < nw && row < n) ? rp[j] : 0ull;
-#endif
+    for (int k = 0; k < NW; ++k) r[k] = bp[k * 64];
   };
-  load_row(cur, 0);
-  unsigned long long mykeep = 0;
-  for (int w = 0; w < nw; ++w) {
-    if (w + 1 < nw) load_row(nxt, w + 1);
-    unsigned long long diag = 0ull;
+  auto stage = [&](const unsigned long long (&r)[NW], int buf, int w) {
+    unsigned long long* dst = &rows[buf][lane >> 5][lane & 31];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) diag = (j == w) ? cur[j] : diag;
-    __syncthreads();   // the LDS atomics of the previous words have landed (one wave: a cheap s_barrier)
+    for (int k = 0; k < NW; ++k) dst[k * 2 * (NW + 1)] = r[k];
+  };
+  load_row(nxt, 0);
+  stage(nxt, 0, 0);
+  __syncthreads();
+  const int myword = lane < NW ? lane : 0;
+  unsigned long long mykeep = 0;
+  int buf = 0;
+  for (int w = 0; w < nw; ++w) {
+#ifndef NMS_ABL_NOLOAD
+    if (w + 1 < nw) load_row(nxt, w + 1);
+#endif
+    const unsigned long long diag = rows[buf][lane][w];
     // Box bb of this word is kept iff bit bb of `c` is clear when its turn comes; a diagonal row only has bits above
     // its own index, so bit bb never changes afterwards and the keep mask is simply ~c at the end: the dependent
     // chain per box is readlane -> select -> or.
-    unsigned long long c = readlane64(rem[w], 0);
+    unsigned long long c = readlane64(myrem, w);
+#ifndef NMS_ABL_NOCHAIN
 #pragma unroll
     for (int bb = 0; bb < 64; ++bb) {
       unsigned long long d = readlane64(diag, bb);
       c |= ((c >> bb) & 1ull) ? 0ull : d;
     }
+#else
+    c |= readlane64(diag, 0);
+#endif
     const unsigned long long keepbits = ~c;
     if (lane == w) mykeep = keepbits;
+    // eight rows per trip, all eight LDS reads in flight before the first OR (a loop over the kept bits alone waits out
+    // the LDS latency once per box); rows of suppressed boxes are read and dropped
+    const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)keepbits);
+    const unsigned khi = __builtin_amdgcn_readfirstlane((unsigned)(keepbits >> 32));
+    unsigned long long acc = 0ull;
 #ifndef NMS_ABL_NOOR
-    if ((keepbits >> lane) & 1ull) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j)
-        if (j > w && j < nw && cur[j]) atomicOr(&rem[j], cur[j]);
-    }
+#else
+    if (klo == 0x12345u)
 #endif
+    for (int ch = 0; ch < 8; ++ch) {
+      const unsigned bits = ((ch < 4 ? klo : khi) >> (8 * (ch & 3))) & 0xffu;
+      if (bits == 0u) continue;
+      unsigned long long v[8];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) cur[j] = nxt[j];
+      for (int t = 0; t < 8; ++t) v[t] = rows[buf][8 * ch + t][myword];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc |= ((bits >> t) & 1u) ? v[t] : 0ull;
+    }
+    if (lane > w && lane < nw) myrem |= acc;
+    if (w + 1 < nw) stage(nxt, buf ^ 1, w + 1);
+    __syncthreads();   // one wave: a cheap s_barrier; the staged rows of word w+1 are visible
+    buf ^= 1;
   }
   int cnt = __popcll(mykeep);
   int incl = cnt;
@@ -280,7 +311,8 @@ extern "C" int mxdet_fpn_level_map(const float* rois, int64_t R, int32_t lvl_min
 extern "C" size_t mxdet_nms_batched_workspace_bytes(int32_t B, int32_t n_max) {
   if (B <= 0 || n_max <= 0) return 0;
   size_t nwords = (size_t)(n_max + 63) / 64;
-  return (size_t)B * n_max * nwords * sizeof(unsigned long long);
+  if (nwords <= 32) nwords = 32;     // the register-row scan reads rows at a fixed 32-word pitch, up to 64 rows past a list
+  return ((size_t)B * n_max + 64) * nwords * sizeof(unsigned long long);
 }
 
 extern "C" int mxdet_nms_batched(const float* boxes, const int32_t* counts, const uint8_t* invalid,
@@ -302,8 +334,9 @@ extern "C" int mxdet_nms_batched(const float* boxes, const int32_t* counts, cons
   MXDET_REQUIRE(workspace && workspace_bytes >= need, MXDET_EWORKSPACE,
                 "nms_batched: workspace %zu < %zu", workspace_bytes, need);
   int nwords = (n_max + 63) / 64;
+  const int pitch = nwords <= 32 ? 32 : nwords;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, B), dim3(64), 0, as_stream(stream),
-                     (const float4*)boxes, counts, n_max, nwords, thresh,
+                     (const float4*)boxes, counts, n_max, pitch, thresh,
                      (unsigned long long*)workspace);
   if (nwords <= 32)
     hipLaunchKernelGGL(nms_scan_rows_kernel<32>, dim3(B), dim3(64), 0, as_stream(stream),

@@ -262,7 +262,9 @@ proposal_merge_kernel(int L, int pre_n, int lvl_cap, int post_n,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* lk = (unsigned long long*)smem_raw;  // [L][lvl_cap]
   __shared__ int nk[8];
-  const int n = blockIdx.x;
+  // grid (L, N): every workgroup stages all of the image's lists (the binary searches need them) and ranks the
+  // elements of ONE level; a single workgroup per image left the other 254 CUs idle for 90-180 us on the critical path
+  const int n = blockIdx.y, l_own = blockIdx.x;
   if (threadIdx.x < L) {
     int v = num_keep[n * L + threadIdx.x];
     nk[threadIdx.x] = v > lvl_cap ? lvl_cap : v;
@@ -276,7 +278,8 @@ proposal_merge_kernel(int L, int pre_n, int lvl_cap, int post_n,
       lk[l * lvl_cap + j] = keys[(long long)b * pre_n + keep_idx[(long long)b * pre_n + j]];
   }
   __syncthreads();
-  for (int l = 0; l < L; ++l) {
+  {
+    const int l = l_own;
     int b = n * L + l;
     for (int j = threadIdx.x; j < nk[l]; j += blockDim.x) {
       unsigned long long e = lk[l * lvl_cap + j];
@@ -304,6 +307,7 @@ proposal_merge_kernel(int L, int pre_n, int lvl_cap, int post_n,
       }
     }
   }
+  if (l_own != 0) return;
   int nout = total < post_n ? total : post_n;
   for (int j = nout + threadIdx.x; j < post_n; j += blockDim.x) {
     float* r = rois + ((long long)n * post_n + j) * 5;
@@ -442,7 +446,7 @@ extern "C" int mxdet_proposal(const mxdet_pyramid_t* p, int32_t N, const float* 
   rc = mxdet_nms_batched((const float*)w.boxes, w.counts, w.invalid, B, pre_nms_top_n, nms_thresh,
                          per_level_post, w.keep_idx, w.num_keep, w.nms_ws, w.nms_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(proposal_merge_kernel, dim3(N), dim3(1024), merge_lds, s, L, pre_nms_top_n,
+  hipLaunchKernelGGL(proposal_merge_kernel, dim3(L, N), dim3(1024), merge_lds, s, L, pre_nms_top_n,
                      per_level_post, post_nms_top_n, w.keys, w.boxes, w.keep_idx, w.num_keep, rois, roi_scores,
                      roi_anchor, num_rois);
   return check_launch("proposal(merge)");
