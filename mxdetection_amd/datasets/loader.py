@@ -173,32 +173,50 @@ class DetectionLoader:
         stop = threading.Event()
 
         def produce():
-            with ThreadPoolExecutor(self.num_workers) as pool:
-                pending = []
-                it = iter(batches)
-                try:
+            # a failing reader must not leave the consumer waiting on the queue: the exception travels through it
+            try:
+                with ThreadPoolExecutor(self.num_workers) as pool:
+                    pending = []
+                    it = iter(batches)
                     for _ in range(self.num_workers):
-                        pending.append(pool.submit(self.assemble, next(it)))
-                except StopIteration:
-                    it = iter(())
-                while pending and not stop.is_set():
-                    hb = pending.pop(0).result()
-                    nxt = next(it, None)
-                    if nxt is not None:
-                        pending.append(pool.submit(self.assemble, nxt))
-                    while not stop.is_set():
-                        try:
-                            host_q.put(hb, timeout=0.1)
+                        nxt = next(it, None)
+                        if nxt is None:
                             break
-                        except queue.Full:
-                            pass
-            host_q.put(None)
+                        pending.append(pool.submit(self.assemble, nxt))
+                    while pending and not stop.is_set():
+                        hb = pending.pop(0).result()
+                        nxt = next(it, None)
+                        if nxt is not None:
+                            pending.append(pool.submit(self.assemble, nxt))
+                        while not stop.is_set():
+                            try:
+                                host_q.put(hb, timeout=0.1)
+                                break
+                            except queue.Full:
+                                pass
+                    for f in pending:
+                        f.cancel()
+                item = None
+            except BaseException as ex:  # noqa: BLE001
+                item = ex
+            while not stop.is_set():
+                try:
+                    host_q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    pass
+
+        def take():
+            item = host_q.get()
+            if isinstance(item, BaseException):
+                raise RuntimeError("the loader's reader thread failed") from item
+            return item
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
         try:
             k, inflight = 0, []
-            hb = host_q.get()
+            hb = take()
             while True:
                 # slots outside `inflight` are free: keep every one of them uploading ahead of the batch handed out
                 while hb is not None and len(inflight) < self.depth:
@@ -206,7 +224,7 @@ class DetectionLoader:
                     self._upload(hb, s)
                     inflight.append(s)
                     k += 1
-                    hb = host_q.get()
+                    hb = take()
                 if not inflight:
                     break
                 s = inflight.pop(0)

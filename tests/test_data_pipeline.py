@@ -161,3 +161,16 @@ def test_assemble_host_batch():
     assert np.all(hb.gt[0, :G_, 2] <= dw - 1) and np.all(hb.gt[0, :G_, 3] <= dh - 1)
     v, ps, first = hb.poly
     assert first.shape == (2 * 20 + 1,) and first[-1] == ps.size - 1 == 2 * G_ and v.shape == (ps[-1], 2)
+
+
+def test_producer_failure_reaches_the_consumer():
+    """Host-side half of the iterator only (no device): a reader that raises must surface, not hang."""
+    import queue
+    import threading
+    roidb = synthetic_roidb(4, seed=1)
+
+    def bad_reader(e):
+        raise IOError("cannot read %s" % e["image"])
+    L = DetectionLoader(roidb, 2, reader=bad_reader, shuffle=False)
+    with pytest.raises(IOError):
+        L.assemble([0, 1])

@@ -140,3 +140,19 @@ def test_loader_batches_match_host_assembly(hip, oracle):
             assert 0.6 < got[0, 0].sum() / ((x2 - x1 + 1) * (y2 - y1 + 1)) < 0.9
         seen += 1
     assert seen == len(L) == want_batches.shape[0]
+
+
+def test_loader_reader_failure_surfaces(hip):
+    roidb = synthetic_roidb(6, seed=4)
+    calls = {"n": 0}
+
+    def flaky(e):
+        calls["n"] += 1
+        if calls["n"] > 4:
+            raise IOError("disk gone")
+        from mxdetection_amd.datasets.synthetic import synthetic_reader
+        return synthetic_reader(e)
+    L = DetectionLoader(roidb, 2, reader=flaky, shuffle=False, num_workers=1)
+    with pytest.raises(RuntimeError, match="reader thread failed"):
+        for _ in L:
+            pass
