@@ -37,22 +37,24 @@ def test_replay_follows_the_scheduled_lr(hip):
     assert not torch.equal(model.arena.m, m1)
 
 
-def test_train_and_test_drivers(hip, tmp_path):
+@pytest.mark.parametrize("cfg_name", ["faster_rcnn_r50_fpn", "mask_rcnn_r50_fpn", "retinanet_r101_fpn"])
+def test_train_and_test_drivers(hip, tmp_path, cfg_name):
     env = dict(os.environ, PYTHONPATH=ROOT)
-    prefix = str(tmp_path / "frcnn")
+    prefix = str(tmp_path / "model")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train.py"), "--cfg",
-                        os.path.join(ROOT, "configs", "faster_rcnn_r50_fpn.yaml"), "dataset.num_images=8", "TRAIN.end_epoch=1",
+                        os.path.join(ROOT, "configs", cfg_name + ".yaml"), "dataset.num_images=8", "TRAIN.end_epoch=1",
                         "TRAIN.log_period=2", "TRAIN.warmup_step=4", "TRAIN.checkpoint_prefix=" + prefix],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("epoch 0 iter")]
     assert len(lines) >= 3 and "saved" in r.stdout
     lrs = [float(l.split(" lr ")[1].split()[0]) for l in lines]
-    assert lrs[0] < lrs[-1] <= 0.0025 + 1e-9                                   # warm-up ramp towards 0.02 * 2/16
+    top = (0.01 if cfg_name.startswith("retinanet") else 0.02) * 2 / 16
+    assert lrs[0] < lrs[-1] <= top + 1e-9                                      # warm-up ramp towards lr * 2/16
     ckpt = prefix + "-0001.params"
     assert os.path.exists(ckpt)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "test.py"), "--cfg",
-                        os.path.join(ROOT, "configs", "faster_rcnn_r50_fpn.yaml"), "--params", ckpt, "--max-images", "4",
+                        os.path.join(ROOT, "configs", cfg_name + ".yaml"), "--params", ckpt, "--max-images", "4",
                         "dataset.num_images=8"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
