@@ -279,6 +279,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = step(args.warmup + i)
+    t_host = time.perf_counter() - t0          # host enqueue time of the timed steps (before the device has drained)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -358,6 +359,7 @@ def main():
             "model_mfma_roofline_frac": (round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4)
                                          if args.model == "faster_rcnn" else None),
             "losses_last_step": loss_vals,
+            "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
             "roofline": roofline,
             "conv_families": families,
         }
