@@ -16,6 +16,8 @@
 // counted s_waitcnt vmcnt and one raw s_barrier per K-step, so 2-3 stages are always in flight.
 // Epilogue: accumulators -> LDS (fp32) -> rows of 8 channels per lane: + bias, + residual
 // (optionally nearest-upsampled: FPN top-down), ReLU / ReLU-mask, bf16 pack, 16-B coalesced stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mxdet {
@@ -557,6 +559,16 @@ conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
 
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
 
+// Tile-choice thresholds. Environment overrides exist because these only tune correctly on whole-step A/B runs (a layer
+// replayed alone keeps its filter in L2 and owns the chip): MXDET_TUNE_T64, _T128, _PAR64.
+static int tune_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+static int thr_t64() { static const int v = tune_int("MXDET_TUNE_T64", 400); return v; }
+static int thr_t128() { static const int v = tune_int("MXDET_TUNE_T128", 1536); return v; }
+static int thr_par64() { static const int v = tune_int("MXDET_TUNE_PAR64", 1600); return v; }
+
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
 static int launch_cfg(ConvP& p, hipStream_t s) {
   if (PAR) {   // rows grouped by parity class: tiles never straddle two classes
@@ -622,12 +634,12 @@ static int launch(ConvP& p, hipStream_t s) {
         p.par_wc[par] = p.Wd > w0 ? (p.Wd - w0 + 1) / 2 : 0;
       }
       if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, true, true>(p, s);
-      if (t64 >= 1600) return launch_cfg<64, 128, 2, 2, 2, true, true>(p, s);
+      if (t64 >= thr_par64()) return launch_cfg<64, 128, 2, 2, 2, true, true>(p, s);
       return launch_cfg<64, 64, 2, 2, 3, true, true>(p, s);
     }
   }
   if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
-  if (t128 >= 1536 && K > 256) {
+  if (t128 >= thr_t128() && K > 256) {
     // Largest layers: 256x256 tiles (one 8-wave workgroup per CU, half the LDS-DMA pieces per MFMA of the 128x128
     // tile) for as many whole rounds of the chip's 256 CUs as the layer has; the remaining rows -- a partial round
     // would leave most CUs idle for a whole tile time -- go to a second launch with 128x128 tiles.
@@ -644,7 +656,7 @@ static int launch(ConvP& p, hipStream_t s) {
     }
     return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
   }
-  if (t64 >= 400) return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
+  if (t64 >= thr_t64()) return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
   return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
 }
 
@@ -773,8 +785,8 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
   // one tile configuration for the whole group, by the same rule as single launches (on the group's totals)
   int cfg;
   if (max_cols <= 64) cfg = 0;
-  else if (t128_max >= 1536 && kmax > 256) cfg = 1;
-  else if (t64 >= 400) cfg = 2;
+  else if (t128_max >= thr_t128() && kmax > 256) cfg = 1;
+  else if (t64 >= thr_t64()) cfg = 2;
   else cfg = 3;
   const int BM = kGroupedTiles[cfg][0], BN = kGroupedTiles[cfg][1];
   long long blocks = 0;
