@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the main stream")
     ap.add_argument("--no-branch-stream", action="store_true", help="keep the RPN training branch on the main stream")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="two launches per layer instead of per bucket")
+    ap.add_argument("--fused-backward", action="store_true",
+                    help="weight-gradient tiles ride in the data-gradient launches of the backward chain")
     ap.add_argument("--input", default="resident", choices=["resident", "loader"],
                     help="resident = batches already in HBM (the headline contract); loader = every step takes its batch from "
                          "datasets.DetectionLoader: host frames -> pinned -> H2D -> preprocess kernel (PCIe-inclusive rate)")
@@ -205,6 +207,8 @@ def main():
         model.enable_branch_stream()
     if not args.no_grouped_wgrad:
         model.enable_grouped_wgrad()
+    if args.fused_backward:
+        model.enable_fused_backward()
     if dist is not None:
         model.enable_data_parallel(world)
         dist.broadcast(model.arena.w, 0)

@@ -367,6 +367,19 @@ int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wg
 int mxdet_debug_force_conv_cfg(int32_t cfg);
 /* Tuning hook: force the split-K factor of mxdet_conv2d_wgrad on the calling thread (0 = heuristic). */
 int mxdet_debug_force_wgrad_ksplit(int32_t ksplit);
+/* Fused backward launch: the data-gradient tiles of a planned conv group (kind 1, tile cfg 2 or 3; table, cfg and
+ * grid from mxdet_conv2d_grouped_plan) and the weight-gradient tiles [w_block_begin, w_block_end) of a planned wgrad
+ * group in ONE grid, so that both kinds of workgroups share the CUs (small-map dgrad launches leave half the chip idle
+ * and do not overlap with another stream's kernels). w_block_begin must be a multiple of 8; the caller issues a
+ * group's remaining tiles and its fold with mxdet_conv2d_wgrad_grouped_from once every fused launch is enqueued. */
+int mxdet_fused_dgrad_wgrad(const void* conv_table_dev, int32_t cn, int32_t cfg, int32_t cgrid,
+                            const void* wgrad_table_dev, int32_t wn, int32_t w_block_begin, int32_t w_block_end,
+                            void* wgrad_workspace, mxdet_stream_t stream);
+/* block0_out[i] = first workgroup of item i of a planned wgrad group (host table), block0_out[n] = its grid */
+int mxdet_conv2d_wgrad_grouped_item_blocks(const void* table_host, int32_t n, int32_t* block0_out);
+int mxdet_conv2d_wgrad_grouped_from(const void* table_dev, int32_t n, int32_t block_begin, int32_t grid_wgrad,
+                                    int32_t grid_reduce, void* workspace, size_t workspace_bytes,
+                                    size_t workspace_needed, mxdet_stream_t stream);
 /* tuning hook: issue a grouped weight-gradient launch in chunks of `workgroups` (0 = one launch) */
 int mxdet_debug_wgrad_group_chunk(int32_t workgroups);
 /* tuning hook: run grouped weight-gradient launches as a persistent grid of `workgroups` (rounded up to 8; 0 = off) */

@@ -129,6 +129,9 @@ SIGNATURES = {
     "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_debug_force_wgrad_ksplit": (c_i32, [c_i32]),
+    "mxdet_fused_dgrad_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mxdet_conv2d_wgrad_grouped_item_blocks": (c_i32, [c_vp, c_i32, c_vp]),
+    "mxdet_conv2d_wgrad_grouped_from": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_debug_wgrad_group_chunk": (c_i32, [c_i32]),
     "mxdet_debug_wgrad_group_persist": (c_i32, [c_i32]),
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

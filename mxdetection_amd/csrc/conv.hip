@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "wgrad_tile.h"
 
 namespace mxdet {
 
@@ -62,8 +63,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // NS-1 stages (48-96 KiB per CU) are in flight and the global-load latency is off the critical path.
 // One counted s_waitcnt vmcnt + one raw s_barrier per K-step; the LDS image is lane-linear, so the
 // conflict-avoiding XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read side.
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
-__device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg) {
+// EXT_LDS: the caller (fused backward kernel) owns one LDS pool that this tile and the weight-gradient tile overlay.
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, bool EXT_LDS = false>
+__device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg,
+                                                unsigned char* lds_pool = nullptr) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -81,7 +84,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
   constexpr int MAIN_BYTES = NBUF * STAGE * 2;
   constexpr int SMEM_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
+  unsigned char* smem_raw;
+  if constexpr (EXT_LDS) {
+    smem_raw = lds_pool;
+  } else {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem_own[SMEM_BYTES];
+    smem_raw = smem_own;
+  }
   uint16_t* smem = (uint16_t*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -557,6 +566,48 @@ conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
   conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false>(p, b, nb);
 }
 
+// Fused backward launch: the data-gradient tiles of a layer (grouped-table form, blocks [0, cgrid)) and a slice of the
+// bucket's weight-gradient tiles (blocks [w_off, w_off + gridDim.x - cgrid_pad) of the grouped wgrad table) in ONE grid.
+// A dgrad launch of a C4/C5-sized layer is 264-528 workgroups, about one per CU, and streams do not overlap it with
+// the weight-gradient stream: here both kinds of workgroups are resident together by
+// construction. cgrid_pad and w_off are multiples of 8 so that every weight-gradient tile keeps its XCD.
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ void __launch_bounds__(256)
+fused_bwd_kernel(const ConvG* __restrict__ ctable, int cn, int cgrid, int cgrid_pad, const WgradG* __restrict__ wtable,
+                 int wn, int w_off, unsigned char* __restrict__ wws) {
+  // one LDS pool, overlaid by the two tile kinds (a workgroup runs exactly one of them)
+  constexpr int CONV_EP = 4 * 32 * (BN / WN + 4) * 4, CONV_MAIN = NS * (BM + BN) * 64 * 2;
+  constexpr int CONV_LDS = CONV_MAIN > CONV_EP ? CONV_MAIN : CONV_EP, WG_LDS = 2 * 2 * kWgradBKP * 256;
+  __shared__ __attribute__((aligned(1024))) unsigned char pool[CONV_LDS > WG_LDS ? CONV_LDS : WG_LDS];
+  const int bid = (int)blockIdx.x;
+  if (bid < cgrid_pad) {
+    if (bid >= cgrid) return;
+    int lo = 0, hi = cn - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (ctable[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int b = bid - ctable[lo].block0;
+    const int nb = ctable[lo].nblocks;
+    if (b >= nb) return;
+    const ConvP p = ctable[lo].p;
+    conv_igemm_tile<BM, BN, WM, WN, NS, true, false, true>(p, b, nb, pool);
+    return;
+  }
+  const int wb = bid - cgrid_pad + w_off;
+  int lo = 0, hi = wn - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (wtable[mid].block0 <= wb) lo = mid; else hi = mid - 1;
+  }
+  const int b = wb - wtable[lo].block0;
+  if (b >= wtable[lo].nblocks) return;
+  WgradP p = wtable[lo].p;
+  p.slab = (float*)(wws + (size_t)p.slab);
+  p.bslab = (float*)(wws + (size_t)p.bslab);
+  wgrad_tile<kWgradBKP, 2, true>(p, b, pool);
+}
+
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
 
 // Tile-choice thresholds. Environment overrides exist because these only tune correctly on whole-step A/B runs (a layer
@@ -827,4 +878,26 @@ extern "C" int mxdet_conv2d_grouped(const void* table_dev, int32_t n, int32_t ki
     }
   }
   return check_launch("conv2d_grouped");
+}
+
+// ---- fused backward launch (see fused_bwd_kernel) ---------------------------------------------------------------------
+extern "C" int mxdet_fused_dgrad_wgrad(const void* conv_table_dev, int32_t cn, int32_t cfg, int32_t cgrid,
+                                       const void* wgrad_table_dev, int32_t wn, int32_t w_block_begin,
+                                       int32_t w_block_end, void* wgrad_workspace, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(conv_table_dev && cn > 0 && cgrid > 0 && wgrad_table_dev && wn > 0 && wgrad_workspace, MXDET_EINVAL,
+                "fused_dgrad_wgrad: null pointer or empty table");
+  MXDET_REQUIRE(cfg == 2 || cfg == 3, MXDET_EINVAL, "fused_dgrad_wgrad: only the 64x128 / 64x64 tile configurations fuse");
+  MXDET_REQUIRE(w_block_begin >= 0 && w_block_end > w_block_begin && w_block_begin % 8 == 0, MXDET_ESHAPE,
+                "fused_dgrad_wgrad: bad weight-gradient block range [%d, %d)", w_block_begin, w_block_end);
+  const int cpad = (cgrid + 7) & ~7;
+  const unsigned grid = (unsigned)(cpad + (w_block_end - w_block_begin));
+  hipStream_t s = as_stream(stream);
+  if (cfg == 2)
+    hipLaunchKernelGGL((fused_bwd_kernel<64, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, (const ConvG*)conv_table_dev, cn,
+                       cgrid, cpad, (const WgradG*)wgrad_table_dev, wn, w_block_begin, (unsigned char*)wgrad_workspace);
+  else
+    hipLaunchKernelGGL((fused_bwd_kernel<64, 64, 2, 2, 3>), dim3(grid), dim3(256), 0, s, (const ConvG*)conv_table_dev, cn,
+                       cgrid, cpad, (const WgradG*)wgrad_table_dev, wn, w_block_begin, (unsigned char*)wgrad_workspace);
+  return check_launch("fused_dgrad_wgrad");
 }

@@ -87,6 +87,7 @@ class FasterRCNN(DetectorBase):
         """image NCHW [N,3,H,W]; gt_boxes [N,G,5] f32 (class < 0 padding); im_info [N,3] f32."""
         N, _, H, W = image.shape
         self.plan(N, H, W, gt_boxes.shape[1])
+        self._begin_step()
         C = self.backbone.forward(image)
         P = self.neck.forward(C)
         self.rpn_head.forward(P)

@@ -187,6 +187,16 @@ class DetectorBase:
         self.world = world_size
         self.reducer = BucketReducer(self.arena.g, dist)
 
+    def enable_fused_backward(self):
+        """Weight-gradient tiles ride in the data-gradient launches of the backward chain (needs grouped wgrad)."""
+        self.enable_grouped_wgrad()
+        self.ws.fusing = True
+
+    def _begin_step(self):
+        self.ws.begin_step()
+        if getattr(self, "ws_rpn", None) is not None:
+            self.ws_rpn.begin_step()
+
     def enable_grouped_wgrad(self):
         """Issue the weight gradients of each bucket (box/mask heads, FPN, every ResNet stage) as one grouped launch."""
         self.ws.grouping = True

@@ -133,6 +133,27 @@ def conv2d_group(kind, calls, device):
             conv2d_dgrad(dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out)
 
 
+def fused_dgrad(call, device, wplan, w_begin, w_end, wbuf):
+    """One data-gradient call (argument tuple of conv2d_dgrad, `out` given) + the weight-gradient tiles
+    [w_begin, w_end) of the planned group `wplan` as ONE launch (mxdet_fused_dgrad_wgrad). Returns False -- nothing
+    launched -- when this call cannot fuse (tile configuration, stride-2 path, table not built before a capture)."""
+    key = ("dgrad1",) + tuple(t.data_ptr() if torch.is_tensor(t) else t for t in call)
+    plan = _group_plans.get(key)
+    if plan is None:
+        if torch.cuda.is_current_stream_capturing() or call[5] != 1:
+            return False
+        try:
+            plan = GroupedConv("dgrad", [call], device)
+        except _lib.MxdetError:
+            plan = False
+        _group_plans[key] = plan
+    if plan is False or plan.cfg not in (2, 3):
+        return False
+    check(_lib.load().mxdet_fused_dgrad_wgrad(ptr(plan.table), plan.n, plan.cfg, plan.grid, ptr(wplan.table), wplan.n,
+                                              w_begin, w_end, ptr(wbuf), stream_ptr()), "fused_dgrad_wgrad")
+    return True
+
+
 class GroupedWgrad:
     """Weight gradients of several layers as one launch pair (mxdet_conv2d_wgrad_grouped). `calls` is a list of
     (x, dy, KH, KW, stride, pad, dw, db, accumulate); the plan (device table, grids, workspace size) is built once, in
@@ -160,6 +181,15 @@ class GroupedWgrad:
               "conv2d_wgrad_grouped_plan")
         self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
         self.n, self.grid_wgrad, self.grid_reduce, self.workspace_bytes = n, gw.value, gr.value, ws.value
+        b0 = (C.c_int32 * (n + 1))()
+        check(lib.mxdet_conv2d_wgrad_grouped_item_blocks(host, n, b0), "conv2d_wgrad_grouped_item_blocks")
+        self.block0 = list(b0)            # first workgroup of every item, [n] = end of the last one (8-aligned)
+
+    def launch_from(self, workspace, block_begin):
+        """The tiles from block_begin on (the earlier ones went out in fused backward launches), then the fold."""
+        check(_lib.load().mxdet_conv2d_wgrad_grouped_from(ptr(self.table), self.n, block_begin, self.grid_wgrad,
+                                                          self.grid_reduce, ptr(workspace), workspace.numel(),
+                                                          self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped_from")
 
     def launch(self, workspace):
         check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_reduce,

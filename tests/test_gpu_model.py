@@ -191,3 +191,30 @@ def test_step_with_an_image_without_ground_truth(hip, kind):
     vals = torch.cat(list(losses)).cpu().numpy()
     assert np.all(np.isfinite(vals)), vals
     assert torch.isfinite(m.arena.g).all()
+
+
+def test_fused_backward_takes_the_same_step(hip):
+    """Experimental schedule (weight-gradient tiles riding in the data-gradient launches, mxdet_fused_dgrad_wgrad):
+    same kernels' arithmetic, so two steps leave bit-identical losses and parameters. (It is slower than the default
+    schedule; kept as a measured alternative.)"""
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    N, H, W = 2, 256, 320
+    image, gt, im_info = _inputs(N, H, W, seed=5)
+
+    def run(fused):
+        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+        m.enable_wgrad_stream()
+        m.enable_grouped_wgrad()
+        if fused:
+            m.enable_fused_backward()
+        out = []
+        for step in range(3):        # step 0 builds the plans, steps 1-2 run fused
+            out.append(torch.cat(m.train_step(image, gt, im_info, step=step, lr=0.001)).clone())
+        torch.cuda.synchronize()
+        return torch.stack(out).cpu(), m.arena.w.clone(), m
+
+    l0, w0, _ = run(False)
+    l1, w1, m = run(True)
+    assert m.ws.flush_plans and any(p is not None for p in m.ws.flush_plans)
+    assert torch.equal(l0, l1) and torch.equal(w0, w1)
