@@ -163,7 +163,7 @@ class DetectorBase:
         with torch.cuda.stream(self.branch):
             # own memory pool: this graph runs concurrently with the main segments, so temporaries allocated while
             # capturing it must not share (time-multiplexed) memory with theirs
-            g.capture_begin(pool=self._pool_branch)
+            g.capture_begin(pool=self._pool_branch, capture_error_mode="thread_local")
             yield
             g.capture_end()
         cur.wait_stream(self.branch)
@@ -220,7 +220,7 @@ class DetectorBase:
                     cur = torch.cuda.current_stream()
                     self.opt_stream.wait_stream(cur)
                     with torch.cuda.stream(self.opt_stream):
-                        g.capture_begin(pool=self._pool_opt)
+                        g.capture_begin(pool=self._pool_opt, capture_error_mode="thread_local")
                         self._apply_update(lo, hi, self._cap_opt, 1.0 / self.world)
                         g.capture_end()
                     cur.wait_stream(self.opt_stream)
@@ -266,7 +266,8 @@ class DetectorBase:
 
     def _seg_begin(self):
         self._cur_graph = torch.cuda.CUDAGraph()
-        self._cur_graph.capture_begin(pool=self._pool)
+        # thread_local: HIP calls of other threads (RCCL's watchdog, loader workers) must not invalidate the capture
+        self._cur_graph.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def _seg_end(self):
         self._cur_graph.capture_end()
