@@ -158,7 +158,8 @@ def coco_bbox_eval(gts, dts, max_dets=(1, 10, 100), _segm=False):
                 sc = np.array([d[i]["score"] for i in do], np.float64)
                 if _segm:
                     db = np.array([np.asarray(d[i]["mask"]) > 0 for i in do], bool).reshape((-1,) + shp)
-                    ious, darea = _iou_masks(db, gb, crowd), db.reshape(db.shape[0], -1).sum(1).astype(np.float64)
+                    ious = _iou_masks(db, gb, crowd)
+                    darea = db.reshape(db.shape[0], -1).sum(1).astype(np.float64) if db.shape[0] else np.zeros((0,))
                 else:
                     db = np.array([d[i]["bbox"] for i in do], np.float64).reshape(-1, 4)
                     ious, darea = _iou_xywh(db, gb, crowd), db[:, 2] * db[:, 3]

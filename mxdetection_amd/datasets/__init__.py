@@ -2,3 +2,4 @@
 from .coco import append_flipped, filter_roidb, load_coco_roidb  # noqa: F401
 from .loader import DetectionLoader, epoch_order  # noqa: F401
 from .synthetic import synthetic_roidb  # noqa: F401
+from .voc import VOC_CLASSES, load_voc_roidb  # noqa: F401

@@ -19,7 +19,7 @@ def build_detector(cfg, device="cuda"):
     return model
 
 
-def build_loader(cfg, device="cuda", rank=0, world=1, train=True):
+def build_loader(cfg, device="cuda", rank=0, world=1, train=True, with_masks=None):
     """Config -> (roidb, class names, DetectionLoader)."""
     import numpy as np
     from ..datasets import append_flipped, filter_roidb, load_coco_roidb, synthetic_roidb
@@ -33,6 +33,10 @@ def build_loader(cfg, device="cuda", rank=0, world=1, train=True):
         roidb, names = load_coco_roidb(ds.ann_file, ds.image_dir)
         # frames are stored as uint8 [h,w,3] .npy arrays next to / instead of the JPEGs (no decoder in the image)
         reader = lambda e: np.load(e["image"] if e["image"].endswith(".npy") else e["image"].rsplit(".", 1)[0] + ".npy")  # noqa: E731
+    elif ds.type == "voc":
+        from ..datasets import load_voc_roidb
+        roidb, names = load_voc_roidb(ds.ann_file, image_dir=ds.image_dir)       # ann_file = the Annotations directory
+        reader = lambda e: np.load(e["image"].rsplit(".", 1)[0] + ".npy")  # noqa: E731
     else:
         raise ValueError("unknown dataset.type %r" % (ds.type,))
     if train:
@@ -44,6 +48,7 @@ def build_loader(cfg, device="cuda", rank=0, world=1, train=True):
                             pad_to=fixed, fit_inside=fixed is not None)
     tr = cfg.TRAIN
     loader = DetectionLoader(roidb, tr.batch_images if train else cfg.TEST.batch_images, device=device, rank=rank, world=world,
-                             reader=reader, preprocessor=pre, g_max=ds.max_gt, with_masks=(train and cfg.network.type == "mask_rcnn"),
+                             reader=reader, preprocessor=pre, g_max=ds.max_gt,
+                             with_masks=(train and cfg.network.type == "mask_rcnn") if with_masks is None else with_masks,
                              shuffle=train and tr.shuffle, aspect_grouping=train and tr.aspect_grouping, seed=tr.seed)
     return roidb, names, loader

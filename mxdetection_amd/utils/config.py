@@ -40,7 +40,7 @@ DEFAULTS = {
         "seed": 7,
     },
     "dataset": {
-        "type": "synthetic",              # synthetic | coco
+        "type": "synthetic",              # synthetic | coco | voc (ann_file = Annotations directory)
         "ann_file": "", "image_dir": "",
         "num_images": 64,                 # synthetic only
         "target_size": 800, "max_size": 1333,

@@ -174,3 +174,26 @@ def test_producer_failure_reaches_the_consumer():
     L = DetectionLoader(roidb, 2, reader=bad_reader, shuffle=False)
     with pytest.raises(IOError):
         L.assemble([0, 1])
+
+
+def test_voc_roidb():
+    from mxdetection_amd.datasets import VOC_CLASSES, load_voc_roidb
+    d = os.path.join(GOLD, "voc_tiny")
+    roidb, names = load_voc_roidb(d, image_dir="JPEGImages")
+    assert names[0] == "__background__" and len(names) == 21 and names[9] == "chair" and names[15] == "person"
+    assert [r["name"] for r in roidb] == ["000005", "000007"]
+    r = roidb[0]
+    assert (r["height"], r["width"]) == (375, 500) and r["image"] == os.path.join("JPEGImages", "000005.jpg")
+    # 1-based inclusive -> 0-based; the difficult chair and the unknown class are dropped; names are case-insensitive
+    assert r["boxes"].tolist() == [[262, 210, 323, 338], [0, 0, 499, 374]] and r["gt_classes"].tolist() == [9, 15]
+    assert roidb[1]["boxes"].shape == (0, 4)
+    keep = load_voc_roidb(d, use_difficult=True)[0][0]
+    assert keep["boxes"].shape[0] == 3 and keep["difficult"].tolist() == [0, 1, 0]
+    lst = os.path.join(d, "set.txt")
+    try:
+        with open(lst, "w") as f:
+            f.write("000007\n")
+        assert [x["name"] for x in load_voc_roidb(d, image_set=lst)[0]] == ["000007"]
+    finally:
+        os.remove(lst)
+    assert len(VOC_CLASSES) == 20

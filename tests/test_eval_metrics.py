@@ -99,3 +99,15 @@ def test_segm_eval_known_answers():
     L[0:20, 20:40] = 0
     r = coco_segm_eval([dict(image_id=1, category_id=1, mask=L)], [dict(image_id=1, category_id=1, mask=rect(0, 0, 40, 40), score=1.0)])
     assert r["AP"] == pytest.approx(0.6)            # IoU 0.75: thresholds 0.50..0.75 (6 of 10)
+
+
+def test_segm_eval_with_missing_detections():
+    """A category / image without any detection (or without ground truth) must not break the mask evaluation."""
+    from mxdetection_amd.core.evaluation import coco_segm_eval
+    m = np.zeros((16, 16), np.uint8)
+    m[2:10, 2:10] = 1
+    gts = [dict(image_id=1, category_id=1, mask=m), dict(image_id=2, category_id=2, mask=m)]
+    dts = [dict(image_id=1, category_id=1, mask=m, score=0.9), dict(image_id=3, category_id=3, mask=m, score=0.5)]
+    r = coco_segm_eval(gts, dts)
+    assert r["AP"] == pytest.approx(0.5)            # category 1 perfect, category 2 missed, category 3 has no ground truth
+    assert coco_segm_eval(gts, [])["AP"] == 0.0

@@ -59,3 +59,5 @@ def test_train_and_test_drivers(hip, tmp_path, cfg_name):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["images"] >= 4 and -1.0 <= res["AP"] <= 1.0 and "AR100" in res
+    if cfg_name.startswith("mask_rcnn"):
+        assert -1.0 <= res["segm"]["AP"] <= 1.0 and "AR100" in res["segm"]
