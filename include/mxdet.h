@@ -269,6 +269,10 @@ int mxdet_mask_target(const float* rois, const int32_t* matched_gt, const int32_
  * conv C_in -> 4*C this is Deconvolution(kernel=2, stride=2). */
 int mxdet_pixel_shuffle2(const uint16_t* x, int64_t R, int32_t H, int32_t W, int32_t C, int32_t inverse,
                          uint16_t* y, mxdet_stream_t stream);
+/* backward of conv1x1 -> ReLU -> pixel shuffle in one pass: dx[r,h,w,(dy*2+dx)*C+c] = dy_up[r,2h+dy,2w+dx,c] where the
+ * packed activation act (same layout as dx, [R,H,W,4*C]) is > 0, else 0 */
+int mxdet_pixel_shuffle2_inv_relu(const uint16_t* dy_up, const uint16_t* act, int64_t R, int32_t H, int32_t W, int32_t C,
+                                  uint16_t* dx, mxdet_stream_t stream);
 /* per-pixel sigmoid BCE on channel cls[r]-1 of logits [R,S,S,Cpad] (bf16), normalised by (#fg rois * S*S);
  * grad (bf16, same shape) is fully written; loss_out[1] fp32, fixed-order reduction. */
 size_t mxdet_mask_loss_workspace_bytes(int64_t R, int32_t S);

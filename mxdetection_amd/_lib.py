@@ -71,6 +71,7 @@ SIGNATURES = {
     "mxdet_generate_anchors": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_nms_batched_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "mxdet_nms_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mxdet_pixel_shuffle2_inv_relu": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_mask_paste_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "mxdet_mask_paste": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_retina_detect_workspace_bytes": (c_sz, [c_vp, c_i32, c_i32]),

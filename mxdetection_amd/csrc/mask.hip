@@ -72,6 +72,33 @@ __global__ void pixel_shuffle2_kernel(const uint4* __restrict__ x, int R, int H,
   if (inverse) y[packed] = x[spread]; else y[spread] = x[packed];
 }
 
+// backward of (1x1 conv -> ReLU -> pixel shuffle): gather the upsampled gradient back into the packed layout and apply
+// the ReLU mask of the packed activation in the same pass (the two separate passes moved the tensor twice more)
+__global__ void pixel_shuffle2_inv_relu_kernel(const uint4* __restrict__ dy_up, const uint4* __restrict__ act, int R,
+                                               int H, int W, int C8, uint4* __restrict__ dx) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)R * H * W * 4 * C8;
+  if (idx >= total) return;
+  int c8 = (int)(idx % C8);
+  long long t = idx / C8;
+  int d = (int)(t & 3);
+  t >>= 2;
+  int w = (int)(t % W);
+  t /= W;
+  int h = (int)(t % H);
+  int r = (int)(t / H);
+  long long spread = ((((long long)r * 2 * H + (2 * h + (d >> 1))) * 2 * W) + (2 * w + (d & 1))) * C8 + c8;
+  const uint4 g = dy_up[spread], a = act[idx];
+  const unsigned gg[4] = {g.x, g.y, g.z, g.w}, aa[4] = {a.x, a.y, a.z, a.w};
+  unsigned o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {     // bf16 > 0  <=>  sign clear and magnitude non-zero
+    const unsigned lo = aa[k] & 0xffffu, hi = aa[k] >> 16;
+    o[k] = ((lo != 0u && lo < 0x8000u) ? (gg[k] & 0xffffu) : 0u) | ((hi != 0u && hi < 0x8000u) ? (gg[k] & 0xffff0000u) : 0u);
+  }
+  dx[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // ---- mask loss: sigmoid BCE on the ground-truth class channel, fused forward + backward -------------------------
 // logits bf16 [R,S,S,Cpad]; cls[r] in 1..num_classes (or -1: ignored roi); targets u8 [R,S,S].
 // grad (bf16, same shape) is written completely (zeros off the class channel). partial[blockIdx] = block loss sum.
@@ -214,6 +241,17 @@ extern "C" int mxdet_pixel_shuffle2(const uint16_t* x, int64_t R, int32_t H, int
   hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3((unsigned)ceil_div<long long>(total, 256)), dim3(256), 0,
                      as_stream(stream), (const uint4*)x, (int)R, H, W, C / 8, inverse, (uint4*)y);
   return check_launch("pixel_shuffle2");
+}
+
+extern "C" int mxdet_pixel_shuffle2_inv_relu(const uint16_t* dy_up, const uint16_t* act, int64_t R, int32_t H, int32_t W,
+                                             int32_t C, uint16_t* dx, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(R > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, MXDET_ESHAPE, "pixel_shuffle2_inv_relu: bad shape");
+  MXDET_REQUIRE(dy_up && act && dx, MXDET_EINVAL, "pixel_shuffle2_inv_relu: null pointer");
+  long long total = (long long)R * H * W * 4 * (C / 8);
+  hipLaunchKernelGGL(pixel_shuffle2_inv_relu_kernel, dim3((unsigned)ceil_div<long long>(total, 256)), dim3(256), 0,
+                     as_stream(stream), (const uint4*)dy_up, (const uint4*)act, (int)R, H, W, C / 8, (uint4*)dx);
+  return check_launch("pixel_shuffle2_inv_relu");
 }
 
 extern "C" size_t mxdet_mask_loss_workspace_bytes(int64_t R, int32_t S) {

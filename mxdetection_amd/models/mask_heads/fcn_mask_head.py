@@ -80,8 +80,7 @@ class FCNMaskHead:
         """Returns d(loss)/d(pooled) bf16 [R,14,14,C]."""
         self.logits.backward_weight(self.up, self.go)
         d_up = self.logits.backward_data(self.go, self.up.shape, out=self._buf("d_up", self.up.shape))
-        d_d4 = dense.pixel_shuffle2(d_up, self._buf("d_d4", self.d4.shape), inverse=True)
-        dense.relu_backward(d_d4, self.d4, d_d4)
+        d_d4 = dense.pixel_shuffle2_inv_relu(d_up, self.d4, self._buf("d_d4", self.d4.shape))
         x = self.acts[-1]
         self.deconv.backward_weight(x, d_d4)
         g = self.deconv.backward_data(d_d4, x.shape, relu_mask=x, out=self._buf("g%d" % len(self.convs), x.shape))

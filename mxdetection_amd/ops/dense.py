@@ -270,6 +270,16 @@ def upsample2_backward(dfine, dcoarse, accumulate=False):
     return dcoarse
 
 
+def pixel_shuffle2_inv_relu(dy_up, act, out=None):
+    """Backward of conv1x1 -> ReLU -> pixel shuffle: dy_up [R,2H,2W,C], act (packed activation) [R,H,W,4C] -> [R,H,W,4C]."""
+    R, H, W, C4 = act.shape
+    if out is None:
+        out = torch.empty_like(act)
+    check(_lib.load().mxdet_pixel_shuffle2_inv_relu(ptr(dy_up), ptr(act), R, H, W, C4 // 4, ptr(out), stream_ptr()),
+          "pixel_shuffle2_inv_relu")
+    return out
+
+
 def pixel_shuffle2(x, out=None, inverse=False):
     """[R,H,W,4C] -> [R,2H,2W,C] (or back with inverse=True): the data movement of a 2x2 stride-2 deconvolution."""
     lib = _lib.load()

@@ -160,3 +160,18 @@ def test_mask_rcnn_predict_with_masks(hip):
         ys, xs = np.nonzero(m[k])
         if ys.size:
             assert xs.min() >= np.rint(d[k, 0]) and xs.max() <= np.rint(d[k, 2]) and ys.min() >= np.rint(d[k, 1]) and ys.max() <= np.rint(d[k, 3])
+
+
+def test_pixel_shuffle_inverse_with_relu_mask(hip):
+    """The fused backward pass equals inverse shuffle followed by the ReLU mask, bit for bit."""
+    from mxdetection_amd.ops import dense
+    g = torch.Generator().manual_seed(2)
+    R, H, W, C = 5, 7, 6, 24
+    dy_up = torch.randn((R, 2 * H, 2 * W, C), generator=g).to(torch.bfloat16).cuda()
+    act = torch.relu(torch.randn((R, H, W, 4 * C), generator=g)).to(torch.bfloat16).cuda()
+    act[0, 0, 0, :8] = 0.0
+    act[0, 0, 0, 8] = -0.0
+    want = dense.pixel_shuffle2(dy_up, inverse=True)
+    want = torch.where(act > 0, want, torch.zeros_like(want))
+    got = dense.pixel_shuffle2_inv_relu(dy_up, act)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
