@@ -107,25 +107,34 @@ mask_loss_kernel(const uint16_t* __restrict__ logits, const int32_t* __restrict_
                  const uint8_t* __restrict__ targets, int R, int SS, int Cpad, const int* __restrict__ num_fg_dev,
                  float loss_scale, uint16_t* __restrict__ grad, float* __restrict__ partial) {
   __shared__ float red[8];
-  const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // A workgroup owns 256 consecutive pixels (the partial-sum layout is unchanged) and walks their Cpad/8 16-byte
+  // gradient chunks with consecutive lanes on consecutive chunks: one lane per pixel writing its whole 176-byte row
+  // left every store instruction scattered over 64 rows.
+  const long long pix0 = (long long)blockIdx.x * 256;
   const long long total = (long long)R * SS;
   const int nfg = *num_fg_dev;   // number of foreground rois, counted on device
   const float norm = 1.0f / (float)((nfg > 0 ? nfg : 1) * SS);
+  const int CH = Cpad >> 3;
   float l = 0.0f;
-  if (pix < total) {
+  for (int it = threadIdx.x; it < 256 * CH; it += 256) {
+    const int pl = it / CH, ck = it - pl * CH;
+    const long long pix = pix0 + pl;
+    if (pix >= total) break;
     const int r = (int)(pix / SS);
     const int c = cls[r];
-    uint16_t* g = grad + pix * Cpad;
-    for (int k = 0; k < Cpad; k += 8) *(uint4*)(g + k) = make_uint4(0u, 0u, 0u, 0u);
-    if (c > 0 && c <= Cpad) {
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (c > 0 && c <= Cpad && ((c - 1) >> 3) == ck) {
       float z = bf16_bits_to_f32(logits[pix * Cpad + (c - 1)]);
       float t = (float)targets[pix];
       float az = z < 0.0f ? -z : z;
       float sp = mxdet_logf(1.0f + mxdet_expf(-az));
-      l = (z > 0.0f ? z : 0.0f) - z * t + sp;
+      l += (z > 0.0f ? z : 0.0f) - z * t + sp;
       float p = z >= 0.0f ? 1.0f / (1.0f + mxdet_expf(-z)) : mxdet_expf(z) / (1.0f + mxdet_expf(z));
-      g[c - 1] = f32_to_bf16_bits((p - t) * norm * loss_scale);
+      const unsigned gb = (unsigned)f32_to_bf16_bits((p - t) * norm * loss_scale) << (16 * ((c - 1) & 1));
+      const int w = ((c - 1) & 7) >> 1;
+      o.x = w == 0 ? gb : 0u; o.y = w == 1 ? gb : 0u; o.z = w == 2 ? gb : 0u; o.w = w == 3 ? gb : 0u;
     }
+    *(uint4*)(grad + pix * Cpad + ck * 8) = o;
   }
   for (int off = 32; off > 0; off >>= 1) l += __shfl_down(l, off);
   int wid = threadIdx.x >> 6;
