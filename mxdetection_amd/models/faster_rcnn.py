@@ -117,7 +117,10 @@ class FasterRCNN(DetectorBase):
             self._join_branch()                                       # dP[l] holds the RPN part
             # the head bucket's weight gradients, update and filter transposes go to the side stream FIRST: they are
             # MFMA / HBM bound and run underneath the gather, which is latency-bound (dependent loads, ~200 us)
-            self._reduce(0, self.mark_rpn)
+            lo = 0
+            if self._bucket_here(0):
+                self._reduce(0, self.mark_rpn)
+                lo = self.mark_rpn
             self.roi_extractor.backward_gather(d_pooled.view(pooled.shape), self.dP[:4], accumulate=True)
             if self.with_mask:
                 self.mask_roi_extractor.backward_gather(d_mpooled, self.dP[:4], accumulate=True)
@@ -128,13 +131,16 @@ class FasterRCNN(DetectorBase):
             self._join_branch()
             self.roi_extractor.finalize(self.dP[:4], accumulate=True)     # dP[l] = RPN part + RoI part
             self._reduce(0, self.mark_rpn)
+            lo = self.mark_rpn
         self.neck.backward(self.dP, self.dC, [False, True, True, True])
-        self._reduce(self.mark_rpn, self.mark_fpn)
-        lo = self.mark_fpn
+        if self._bucket_here(1):
+            self._reduce(lo, self.mark_fpn)
+            lo = self.mark_fpn
         for si in (3, 2, 1):
             self._backbone_stage_backward(si)
-            self._reduce(lo, self.stage_marks[si])
-            lo = self.stage_marks[si]
+            if si == 1 or self._bucket_here(5 - si):       # reduce points 2 (layer4), 3 (layer3); layer2 always closes
+                self._reduce(lo, self.stage_marks[si])
+                lo = self.stage_marks[si]
         if self.with_mask:
             return rpn_loss, rcnn_loss, mask_loss
         return rpn_loss, rcnn_loss

@@ -64,10 +64,14 @@ class RetinaNet(DetectorBase):
         self.head.forward(P)
         loss = self.head.loss_and_grad(gt_boxes, im_info)
         self.head.backward(self.dP)
-        self._reduce(0, self.mark_head)
+        lo = 0
+        if self._bucket_here(0):
+            self._reduce(0, self.mark_head)
+            lo = self.mark_head
         self.neck.backward(self.dP, self.dC[1:])
-        self._reduce(self.mark_head, self.mark_fpn)
-        lo = self.mark_fpn
+        if self._bucket_here(1):
+            self._reduce(lo, self.mark_fpn)
+            lo = self.mark_fpn
         for si in (3, 2, 1):
             stage = self.backbone.stages[si]
             ds = self.dC[si]
@@ -79,6 +83,7 @@ class RetinaNet(DetectorBase):
                     b.backward(ds, self.dC[si - 1], True)
                 else:
                     b.backward(ds, None, False)
-            self._reduce(lo, self.stage_marks[si])
-            lo = self.stage_marks[si]
+            if si == 1 or self._bucket_here(5 - si):
+                self._reduce(lo, self.stage_marks[si])
+                lo = self.stage_marks[si]
         return (loss,)

@@ -1,6 +1,7 @@
 """Shared training-step machinery of the detectors: parameter arena bookkeeping, bucketed gradient exchange, hipGraph
 capture / replay of the whole step, side-stream weight gradients, optimizer step."""
 import contextlib
+import os
 
 import torch
 
@@ -21,6 +22,8 @@ class DetectorBase:
         self._cur_graph = None
         self._tr_table = None
         self.static_extra = {}
+        # single GPU: no exchange to overlap, so everything behind the heads is ONE bucket (see _bucket_here)
+        self.bucket_merge = os.environ.get("MXDET_TUNE_BUCKETS", "123")
         self.branch = None
         self._upd = None          # (lr, momentum, wd) while a training step wants its buckets updated as they finish
         self._upd_done = []       # arena ranges already updated in this step
@@ -186,6 +189,16 @@ class DetectorBase:
         self.dist = dist
         self.world = world_size
         self.reducer = BucketReducer(self.arena.g, dist)
+        # with a gradient exchange the buckets stay fine (every all-reduce but the last overlaps the rest of backward);
+        # only the FPN and layer4 buckets are merged
+        self.bucket_merge = os.environ.get("MXDET_TUNE_BUCKETS", "1")
+
+    def _bucket_here(self, point):
+        """Reduce points of backward, in order: 0 heads, 1 FPN, 2 layer4, 3 layer3 (layer2 always closes the last
+        bucket). A point named in bucket_merge does not close its bucket: the parameters join the next one. Fewer,
+        larger buckets mean fewer and better-filled grouped weight-gradient / fold / update launches and fewer
+        interruptions of the dgrad chain (whole-step A/B: +1.3…2 % for two buckets instead of five at N = 1)."""
+        return str(point) not in self.bucket_merge
 
     def enable_fused_backward(self):
         """Weight-gradient tiles ride in the data-gradient launches of the backward chain (needs grouped wgrad)."""
