@@ -81,11 +81,20 @@ class RPNHead:
     def get_proposals(self, im_info):
         return self.proposal(self.h, self.h, im_info, layout="nhwc_fused")
 
-    def loss_and_grad(self, gt_boxes, im_info, step, image_offset, loss_scale=1.0, step_dev=None):
-        """Assign anchors, compute the RPN losses and d(loss)/d(head) for every level (bf16)."""
+    def assign_targets(self, gt_boxes, im_info, step, image_offset, step_dev=None):
+        """Anchor labels / regression targets. They depend on the ground truth and the anchor grid only -- not on any
+        network output -- so the caller may issue this long before the head has run."""
         labels, _, targets, _ = A_.assign_anchor(self.anchors, gt_boxes, im_info, self.fg_thresh, self.bg_thresh, 0.0,
                                                  self.batch_size, self.fg_fraction, self.seed, step, image_offset,
                                                  self.at_ws, self.at_out, step_dev)
+        self._assigned = (labels, targets)
+
+    def loss_and_grad(self, gt_boxes, im_info, step, image_offset, loss_scale=1.0, step_dev=None, assigned=False):
+        """Assign anchors (unless assign_targets() already ran for this step), compute the RPN losses and
+        d(loss)/d(head) for every level (bf16)."""
+        if not assigned:
+            self.assign_targets(gt_boxes, im_info, step, image_offset, step_dev)
+        labels, targets = self._assigned
         N = gt_boxes.shape[0]
         norm = 1.0 / float(N * self.batch_size)
         self.gh = []
