@@ -108,8 +108,9 @@ class RPNHead:
         L_.loss_finalize(self.partial, off, 2, self.loss)
         return self.loss
 
-    def backward(self, dP, dP_has_grad):
-        """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False)."""
+    def backward(self, dP, dP_has_grad, flush=True):
+        """Adds the RPN branch's gradient into dP[l] (overwrites where dP_has_grad[l] is False). flush=False leaves the
+        recorded weight gradients pending in the workspace: the caller issues them later (ws.flush())."""
         L = len(self.h)
         dt = [self._buf("dt%d" % l, self.t[l].shape) for l in range(L)]
         grouped = self.out.ws.grouping     # grouped form: the plan sums the levels of a shared filter itself
@@ -123,4 +124,5 @@ class RPNHead:
         self.conv.backward_data(dt[0], self.P[0].shape, accumulate=dP_has_grad[0], out=dP[0])
         dense.conv2d_group("dgrad", [self.conv.dgrad_call(dt[l], self.P[l].shape, accumulate=dP_has_grad[l], out=dP[l])
                                      for l in range(1, L)], self.device)
-        self.out.ws.flush()
+        if flush:
+            self.out.ws.flush()

@@ -218,7 +218,11 @@ class DetectorBase:
 
     def _reduce(self, lo, hi):
         self.ws.flush()           # grouped mode: the bucket's recorded weight gradients go out now
-        self.ws.join()            # the bucket's weight gradients were produced on the side stream
+        if self.dist is not None:
+            # the all-reduce is ordered on the main stream: wait for the side stream's weight gradients. Without an
+            # exchange the bucket's update follows its weight gradients ON the side stream and the main stream never
+            # waits (optimizer_step / segment ends join the side stream).
+            self.ws.join()
         if self._cap:
             if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
                 self._seg_end()
