@@ -104,11 +104,10 @@ class FasterRCNN(DetectorBase):
         # The RPN training branch (anchor targets, RPN losses, RPN head backward: MFMA-heavy) depends only on the
         # head outputs; the proposal -> RoI -> box-head chain (long, low-occupancy selection/NMS kernels) does not
         # depend on it. They run on two streams and meet at dP.
-        # Single GPU: the RPN head's weight gradients leave the branch and run on the side stream underneath the RoIAlign
-        # gather (+0.8 % on the step). With a gradient exchange the main stream waits for the bucket's weight gradients
-        # before the all-reduce, so they stay in the branch.
-        defer_rpn = (self.dist is None and self.roi_bwd_gather and self.ws.side is not None and self.ws_rpn.grouping
-                     and os.environ.get("MXDET_TUNE_DEFER_RPN_WGRAD", "1") == "1")
+        # The RPN head's weight gradients leave the branch and run on the side stream, with the head bucket, underneath
+        # the RoIAlign gather (+0.8 % on the step).
+        defer_rpn = (self.roi_bwd_gather and self.ws.side is not None and self.ws_rpn.grouping and self.ws.grouping
+                     and self._bucket_here(0) and os.environ.get("MXDET_TUNE_DEFER_RPN_WGRAD", "1") == "1")
         with self._branch_ctx():
             rpn_loss = self.rpn_head.loss_and_grad(gt_boxes, im_info, step, image_offset, step_dev=step_dev, assigned=early)
             self.rpn_head.backward(self.dP, [False] * 5, flush=not defer_rpn)
@@ -130,16 +129,13 @@ class FasterRCNN(DetectorBase):
         d_pooled = self.bbox_head.backward()
         if self.roi_bwd_gather:
             self._join_branch()                                       # dP[l] holds the RPN part
-            if defer_rpn:
-                # the RPN head's weight gradients (MFMA-bound, 285 us) go to the side stream here, underneath the
-                # gather, instead of lengthening the branch
-                self.ws_rpn.side = self.ws.side
-                self.ws_rpn.flush()
+            # (defer_rpn: the RPN head's weight gradients -- MFMA-bound, 285 us -- go to the side stream with this bucket,
+            # underneath the gather, instead of lengthening the branch)
             # the head bucket's weight gradients, update and filter transposes go to the side stream FIRST: they are
             # MFMA / HBM bound and run underneath the gather, which is latency-bound (dependent loads, ~200 us)
             lo = 0
             if self._bucket_here(0):
-                self._reduce(0, self.mark_rpn)
+                self._reduce(0, self.mark_rpn, pre=self.ws_rpn if defer_rpn else None)
                 lo = self.mark_rpn
             self.roi_extractor.backward_gather(d_pooled.view(pooled.shape), self.dP[:4], accumulate=True)
             if self.with_mask:

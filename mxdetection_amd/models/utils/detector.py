@@ -216,19 +216,46 @@ class DetectorBase:
         if getattr(self, "ws_rpn", None) is not None:
             self.ws_rpn.grouping = True
 
-    def _reduce(self, lo, hi):
-        self.ws.flush()           # grouped mode: the bucket's recorded weight gradients go out now
-        if self.dist is not None:
-            # the all-reduce is ordered on the main stream: wait for the side stream's weight gradients. Without an
-            # exchange the bucket's update follows its weight gradients ON the side stream and the main stream never
-            # waits (optimizer_step / segment ends join the side stream).
-            self.ws.join()
+    def _reduce(self, lo, hi, pre=None):
+        """Close the gradient bucket [lo, hi). pre: another workspace whose recorded weight gradients belong to this
+        bucket and go out first, on the same stream (the RPN head's, when they were not issued inside the branch)."""
+        side_graph = (self._cap and self.dist is not None and hi > lo and self.ws.side is not None and self.ws.grouping
+                      and bool(self.ws.pending) and os.environ.get("MXDET_TUNE_WGRAD_GRAPH", "1") == "1")
+        if not side_graph:
+            if pre is not None:
+                pre.side = self.ws.side
+                pre.flush()
+            self.ws.flush()           # grouped mode: the bucket's recorded weight gradients go out now
+            if self.dist is not None:
+                # the all-reduce is ordered on the main stream: wait for the side stream's weight gradients. Without an
+                # exchange the bucket's update follows its weight gradients ON the side stream and the main stream never
+                # waits (optimizer_step / segment ends join the side stream).
+                self.ws.join()
         if self._cap:
             if self.dist is not None and hi > lo:   # cut the graph here: the all-reduce runs between segments
                 self._seg_end()
                 k = len(self._buckets)
                 self._buckets.append((lo, hi))
-                self.segments.append(("reduce", lo, hi, k))
+                if side_graph:
+                    # The bucket's weight gradients become a graph of their own, replayed on the side stream behind an
+                    # event of the main stream; the all-reduce is then issued from the side stream. Left inside the main
+                    # segment they would sit at its tail, and the next segment -- the rest of the dgrad chain -- would
+                    # wait for them at every bucket.
+                    g = torch.cuda.CUDAGraph()
+                    cur = torch.cuda.current_stream()
+                    side, self.ws.side = self.ws.side, None
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        g.capture_begin(pool=self._pool_w, capture_error_mode="thread_local")
+                        if pre is not None:
+                            pre.side = None
+                            pre.flush()
+                        self.ws.flush()
+                        g.capture_end()
+                    cur.wait_stream(side)
+                    self.ws.side = side
+                    self.segments.append(("wgrad", g))
+                self.segments.append(("reduce", lo, hi, k, side_graph))
                 if self._cap_opt is not None:
                     # The bucket's update is a small graph of its own, replayed on the optimizer stream once that
                     # stream has waited for the bucket's all-reduce: it overlaps the rest of backward exactly like
@@ -307,6 +334,7 @@ class DetectorBase:
         self._pool = torch.cuda.graph_pool_handle()
         self._pool_branch = torch.cuda.graph_pool_handle()
         self._pool_opt = torch.cuda.graph_pool_handle()
+        self._pool_w = torch.cuda.graph_pool_handle()
         self.segments = []
         self._buckets = []
         self._cap_opt = None
@@ -352,8 +380,18 @@ class DetectorBase:
         handles = {}
         for seg in self.segments:
             if isinstance(seg, tuple):
-                if seg[0] == "reduce":
-                    h = self.reducer.reduce(seg[1], seg[2])
+                if seg[0] == "wgrad":
+                    ev = torch.cuda.Event()
+                    ev.record()                               # behind the segment that produced the bucket's dy / x
+                    self.ws.side.wait_event(ev)
+                    with torch.cuda.stream(self.ws.side):
+                        seg[1].replay()
+                elif seg[0] == "reduce":
+                    if len(seg) > 4 and seg[4]:               # ordered behind the side stream's weight gradients
+                        with torch.cuda.stream(self.ws.side):
+                            h = self.reducer.reduce(seg[1], seg[2])
+                    else:
+                        h = self.reducer.reduce(seg[1], seg[2])
                     if len(seg) > 3:
                         handles[seg[3]] = h
                 elif seg[0] == "update":
@@ -363,6 +401,8 @@ class DetectorBase:
                         seg[1].replay()
                 elif seg[0] == "join_opt":
                     torch.cuda.current_stream().wait_stream(self.opt_stream)
+                    if self.ws.side is not None:
+                        torch.cuda.current_stream().wait_stream(self.ws.side)
                     self.reducer.pending, self.reducer.log = [], []
                 elif seg[0] == "fork":
                     fork_ev = torch.cuda.Event()
