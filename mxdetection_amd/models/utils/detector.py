@@ -189,9 +189,9 @@ class DetectorBase:
         self.dist = dist
         self.world = world_size
         self.reducer = BucketReducer(self.arena.g, dist)
-        # with a gradient exchange the buckets stay fine (every all-reduce but the last overlaps the rest of backward);
-        # only the FPN and layer4 buckets are merged
-        self.bucket_merge = os.environ.get("MXDET_TUNE_BUCKETS", "1")
+        # with a gradient exchange the buckets stay fine (five: every all-reduce but the last overlaps the rest of
+        # backward); their weight gradients run as side-stream graphs (_reduce), so fine buckets cost nothing here
+        self.bucket_merge = os.environ.get("MXDET_TUNE_BUCKETS", "")
 
     def _bucket_here(self, point):
         """Reduce points of backward, in order: 0 heads, 1 FPN, 2 layer4, 3 layer3 (layer2 always closes the last
