@@ -153,6 +153,53 @@ def cpu_baseline(rank):
     return model_ref.timed_cpu_baseline()
 
 
+def spawn_ranks(n):
+    """Launcher for `python bench.py --gpus N` without torch.distributed.run: one child per GPU with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1. Children are new processes (never a re-exec of one that
+    initialised the GPU). Returns the exit code: 0 only if every rank exited 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others waiting in a collective: stop them (exact PIDs) instead of hanging
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed (rank, exit code): %s\n" % bad)
+        first = [rc for _, rc in bad if rc > 0]
+        return first[0] if first and first[0] < 256 else 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,10 +220,19 @@ def main():
                     help="faster_rcnn = BASELINE.json headline (configs 1-3); mask_rcnn = config 4; retinanet = config 5 (R101)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes a launcher. It starts N fresh rank processes BEFORE
+        # anything here touches the GPU (no torch import yet), relays rank 0's JSON line and fails if any rank fails.
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    if ndev < max(1, min(world, local_rank + 1)) or (world > 1 and ndev < world):
+        sys.stderr.write("bench.py: --gpus %d needs %d visible devices on this node, found %d\n" % (args.gpus, world, ndev))
+        sys.exit(3)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     device = "cuda"

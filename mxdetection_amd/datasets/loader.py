@@ -35,15 +35,15 @@ def epoch_order(roidb, global_batch, epoch, seed=0, shuffle=True, aspect_groupin
         groups = []
         for sel in (np.where(horz)[0], np.where(~horz)[0]):
             sel = rng.permutation(sel)
-            if sel.size % global_batch:                      # fill the group's last batch from its own start
-                sel = np.concatenate([sel, sel[:global_batch - sel.size % global_batch]]) if sel.size else sel
+            if sel.size % global_batch:                      # fill the group's last batch from its own start, cyclically
+                sel = np.resize(sel, sel.size + global_batch - sel.size % global_batch)   # (the group may be smaller than the pad)
             groups.append(sel.reshape(-1, global_batch))
         rows = np.concatenate(groups, 0)
         order = rows[rng.permutation(rows.shape[0])].reshape(-1)
     else:
         order = rng.permutation(n)
     if order.size % global_batch:
-        order = np.concatenate([order, order[:global_batch - order.size % global_batch]])
+        order = np.resize(order, order.size + global_batch - order.size % global_batch)   # cyclic: n may be < the pad
     return order.astype(np.int64)
 
 

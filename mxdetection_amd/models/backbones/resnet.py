@@ -9,7 +9,7 @@ backward ReLU / shortcut add is fused into a dgrad epilogue.
 import torch
 
 from ...ops import dense
-from ..utils.layers import ConvLayer
+from ..utils.layers import ConvLayer, cached_buf
 
 
 class Bottleneck:
@@ -30,11 +30,7 @@ class Bottleneck:
         return [l for l in (self.conv3, self.conv2, self.conv1, self.down) if l is not None]
 
     def _buf(self, key, shape):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = torch.empty(shape, dtype=torch.bfloat16, device=self.conv1.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, torch.bfloat16, self.conv1.device)
 
     def plan(self, x_shape):
         s1 = self.conv1.out_shape(x_shape)
@@ -131,10 +127,13 @@ class ResNet:
 
     def forward(self, image):
         """image: NCHW [N,3,H,W] (f32 or bf16), read directly by the stem kernel."""
-        x = dense.stem_conv7x7(image, self.stem_w, self.stem_b, self.bufs.get("stem"))
-        self.bufs["stem"] = x
-        x = dense.maxpool3x3s2(x, self.bufs.get("pool"))
-        self.bufs["pool"] = x
+        N, _, H, W = image.shape
+        H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dev = self.stem_w.device
+        x = dense.stem_conv7x7(image, self.stem_w, self.stem_b,
+                               cached_buf(self.bufs, "stem", (N, H1, W1, 64), torch.bfloat16, dev))
+        x = dense.maxpool3x3s2(x, cached_buf(self.bufs, "pool", (N, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1, 64),
+                                             torch.bfloat16, dev))
         outs = []
         for st in self.stages:
             for b in st:

@@ -8,7 +8,7 @@ import torch
 
 from ...core import bbox as B_
 from ...core import loss as L_
-from ..utils.layers import ConvLayer
+from ..utils.layers import ConvLayer, cached_buf
 
 
 class BBoxHead:
@@ -19,7 +19,7 @@ class BBoxHead:
         self.nc = num_classes
         self.reg_dim = 4 * num_classes
         self.ld = (num_classes + self.reg_dim + 63) // 64 * 64
-        self.fc_out = ConvLayer("bbox.fc_out", fc_dim, self.ld, 1, init_std=0.01, **kw)
+        self.fc_out = ConvLayer("bbox.fc_out", fc_dim, self.ld, 1, init_std=0.01, cout_real=num_classes + self.reg_dim, **kw)
         self.fc2 = ConvLayer("bbox.fc2", fc_dim, fc_dim, 1, **kw)
         self.fc1 = ConvLayer("bbox.fc1", in_features, fc_dim, 1, **kw)
         self.R, self.fg_fraction, self.fg_thresh, self.bg_hi, self.bg_lo = rois_per_image, fg_fraction, fg_thresh, bg_hi, bg_lo
@@ -31,11 +31,7 @@ class BBoxHead:
         return [self.fc_out, self.fc2, self.fc1]
 
     def _buf(self, key, shape, dtype=torch.bfloat16, zero=False):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, dtype, self.device, zero)
 
     def plan(self, N):
         R = N * self.R

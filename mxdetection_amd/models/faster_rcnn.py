@@ -66,6 +66,7 @@ class FasterRCNN(DetectorBase):
         key = (N, H, W, g_max)
         if self.planned == key:
             return
+        self._guard_replan(key)
         dev = self.device
         c_shapes = self.backbone.plan((N, 3, H, W))
         self.neck.plan(c_shapes)

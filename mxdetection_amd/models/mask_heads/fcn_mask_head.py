@@ -9,7 +9,7 @@ import torch
 
 from ...core import mask as M_
 from ...ops import dense
-from ..utils.layers import ConvLayer
+from ..utils.layers import ConvLayer, cached_buf
 
 
 class FCNMaskHead:
@@ -18,7 +18,7 @@ class FCNMaskHead:
         self.nc, self.S, self.Rimg, self.device, self.C = num_classes, size, rois_per_image, device, channels
         self.cpad = (num_classes - 1 + 63) // 64 * 64
         # registration = backward completion order
-        self.logits = ConvLayer("mask.logits", channels, self.cpad, 1, init_std=0.001, **kw)
+        self.logits = ConvLayer("mask.logits", channels, self.cpad, 1, init_std=0.001, cout_real=num_classes - 1, **kw)
         self.deconv = ConvLayer("mask.deconv", channels, 4 * channels, 1, **kw)   # 2x2/2 deconv as 1x1 conv + shuffle
         self.convs = [ConvLayer("mask.conv%d" % i, channels, channels, 3, **kw) for i in reversed(range(num_convs))][::-1]
         self.bufs = {}
@@ -27,11 +27,7 @@ class FCNMaskHead:
         return [self.logits, self.deconv] + list(reversed(self.convs))
 
     def _buf(self, key, shape, dtype=torch.bfloat16, zero=False):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, dtype, self.device, zero)
 
     def plan(self, N):
         R = N * self.Rimg

@@ -7,7 +7,7 @@ read nearest-neighbour as the residual), so the merged map is written once and n
 import torch
 
 from ...ops import dense
-from ..utils.layers import ConvLayer
+from ..utils.layers import ConvLayer, cached_buf
 
 
 class FPN:
@@ -34,11 +34,7 @@ class FPN:
             self.outs[i].plan((s[0], s[1], s[2], self.C))
 
     def _buf(self, key, shape):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, torch.bfloat16, self.device)
 
     def forward(self, feats):
         L = self.L
@@ -104,11 +100,7 @@ class RetinaFPN:
         return [self.p7] + self.outs + [self.p6] + self.lats
 
     def _buf(self, key, shape):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, torch.bfloat16, self.device)
 
     def plan(self, c_shapes):
         for i, s in enumerate(c_shapes):

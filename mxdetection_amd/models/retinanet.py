@@ -30,6 +30,7 @@ class RetinaNet(DetectorBase):
         key = (N, H, W, g_max)
         if self.planned == key:
             return
+        self._guard_replan(key)
         c_shapes = self.backbone.plan((N, 3, H, W))
         p_shapes = self.neck.plan(c_shapes[1:])
         self.head.plan(p_shapes, g_max)

@@ -15,6 +15,7 @@ class FPNRoIExtractor:
         self.lvl_max = lvl_min + len(strides) - 1
         self.device = device
         self.out = None
+        self.outs = {}
         self.dacc = None
 
     def forward(self, feats, rois):
@@ -22,8 +23,11 @@ class FPNRoIExtractor:
         self.feats, self.rois = feats[:len(self.scales)], rois
         self.levels = fpn_level_map(rois, self.lvl_min, self.lvl_max)
         R, C = rois.shape[0], feats[0].shape[3]
-        if self.out is None or self.out.shape[0] != R:
+        # keyed by shape: a call with another roi count (inference) must not free the buffer a captured step writes
+        self.out = self.outs.setdefault((R, C), None)
+        if self.out is None:
             self.out = torch.empty((R, self.pooled[0], self.pooled[1], C), dtype=torch.bfloat16, device=self.device)
+            self.outs[(R, C)] = self.out
         return roi_align_forward(self.feats, self.scales, rois, self.levels, self.pooled, self.sr, self.lvl_min, self.out)
 
     def backward(self, grad_out, dP, shared_acc=None, zero=True, finalize=True):

@@ -12,7 +12,7 @@ import torch
 from ...core import anchor as A_
 from ...core import loss as L_
 from ...ops import dense
-from ..utils.layers import ConvLayer
+from ..utils.layers import ConvLayer, cached_buf
 
 
 class RetinaHead:
@@ -24,8 +24,8 @@ class RetinaHead:
         self.ld_cls = (self.A * num_classes + 63) // 64 * 64
         self.ld_reg = (self.A * 4 + 63) // 64 * 64
         # registration = backward completion order
-        self.cls_out = ConvLayer("retina.cls_out", channels, self.ld_cls, 3, init_std=0.01, **kw)
-        self.box_out = ConvLayer("retina.box_out", channels, self.ld_reg, 3, init_std=0.01, **kw)
+        self.cls_out = ConvLayer("retina.cls_out", channels, self.ld_cls, 3, init_std=0.01, cout_real=self.A * num_classes, **kw)
+        self.box_out = ConvLayer("retina.box_out", channels, self.ld_reg, 3, init_std=0.01, cout_real=self.A * 4, **kw)
         self.cls_convs = [ConvLayer("retina.cls%d" % i, channels, channels, 3, init_std=0.01, **kw)
                           for i in reversed(range(num_convs))][::-1]
         self.box_convs = [ConvLayer("retina.box%d" % i, channels, channels, 3, init_std=0.01, **kw)
@@ -47,11 +47,7 @@ class RetinaHead:
         b[: self.A * self.Cn] = self.prior_bias      # focal-loss prior: every anchor starts at p = 0.01
 
     def _buf(self, key, shape, dtype=torch.bfloat16, zero=False):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, dtype, self.device, zero)
 
     def plan(self, p_shapes, g_max):
         for s in p_shapes:

@@ -11,7 +11,7 @@ from ...core import anchor as A_
 from ...core import loss as L_
 from ...ops import dense
 from ...ops.proposal import PyramidProposal
-from ..utils.layers import ConvLayer
+from ..utils.layers import ConvLayer, cached_buf
 
 HEAD_CPAD = 64   # fused cls+reg output channels padded so that dgrad's reduction dim is a multiple of 64
 
@@ -23,7 +23,7 @@ class RPNHead:
         kw = dict(arena=arena, ws=ws, device=device, gen=gen)
         self.A = len(ratios) * len(scales)
         assert 5 * self.A <= HEAD_CPAD
-        self.out = ConvLayer("rpn.out", channels, HEAD_CPAD, 1, init_std=0.01, **kw)
+        self.out = ConvLayer("rpn.out", channels, HEAD_CPAD, 1, init_std=0.01, cout_real=5 * self.A, **kw)
         self.conv = ConvLayer("rpn.conv", channels, channels, 3, init_std=0.01, **kw)
         self.strides = list(strides)
         self.base = [torch.from_numpy(A_.generate_base_anchors(s, ratios, scales)).to(device) for s in strides]
@@ -38,11 +38,7 @@ class RPNHead:
         return [self.out, self.conv]
 
     def _buf(self, key, shape, dtype=torch.bfloat16, zero=False):
-        b = self.bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self.bufs[key] = b
-        return b
+        return cached_buf(self.bufs, key, shape, dtype, self.device, zero)
 
     def plan(self, p_shapes, g_max):
         for s in p_shapes:

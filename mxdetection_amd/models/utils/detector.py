@@ -2,6 +2,7 @@
 capture / replay of the whole step, side-stream weight gradients, optimizer step."""
 import contextlib
 import os
+import warnings
 
 import torch
 
@@ -205,6 +206,12 @@ class DetectorBase:
         self.enable_grouped_wgrad()
         self.ws.fusing = True
 
+    def _guard_replan(self, key):
+        """plan() at a new input shape reallocates buffers a captured step holds by address."""
+        if self.segments is not None and self.planned is not None and self.planned != key:
+            raise RuntimeError("the captured training step holds the buffers planned for %s; a call at %s would free "
+                               "them (build a second model for another input shape)" % (self.planned, key))
+
     def _begin_step(self):
         self.ws.begin_step()
         if getattr(self, "ws_rpn", None) is not None:
@@ -314,23 +321,48 @@ class DetectorBase:
         self._cur_graph.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def _seg_end(self):
-        self._cur_graph.capture_end()
-        self.segments.append(self._cur_graph)
+        """Close the current segment. A segment in which nothing was launched (the step opens with a fork to the branch
+        stream) is dropped instead of being replayed as an empty graph every step; torch reports that case with a
+        warning at capture_end, which is the only place the node count is visible from Python."""
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            self._cur_graph.capture_end()
+        empty = False
+        for w in rec:
+            if "Graph is empty" in str(w.message):
+                empty = True
+            else:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if not empty:
+            self.segments.append(self._cur_graph)
         self._cur_graph = None
 
     # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
-    def capture(self, image, gt_boxes, im_info, lr, image_offset=0, warmup=2, gt_masks=None):
+    def capture(self, image, gt_boxes, im_info, lr, image_offset=0, warmup=2, gt_masks=None, momentum=0.9, wd=1e-4):
         """Capture forward+backward+update into hipGraph segments (cut only at gradient all-reduces).
-        The RNG step counter is read from device memory (step_dev), inputs from static buffers."""
+        The RNG step counter is read from device memory (step_dev), inputs from static buffers. momentum / wd are
+        baked into the captured update kernels (lr is read from device memory: replay(lr=...)). The eager warm-up
+        steps plan shapes and allocate buffers only: parameters and momentum are restored afterwards, so replay(step=0)
+        is the first training step, exactly as train_step(step=0) on a fresh model would be."""
         dev = self.device
+        hyper = (float(momentum), float(wd))
         self.static_in = (image.clone(), gt_boxes.clone(), im_info.clone())
         self.static_masks = gt_masks.clone() if gt_masks is not None else None
         self.step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)   # replay(lr=...) rewrites it
         self._lr_host = lr
+        snap = (self.arena.w.clone(), self.arena.m.clone()) if warmup > 0 else None
         for i in range(warmup):     # eager warm-up: plans shapes and allocates every buffer
-            self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr, gt_masks=self.static_masks)
+            self.train_step(*self.static_in, step=i, image_offset=image_offset, lr=lr, gt_masks=self.static_masks,
+                            momentum=hyper[0], wd=hyper[1])
         torch.cuda.synchronize()
+        if snap is not None:
+            self.arena.w.copy_(snap[0])
+            self.arena.m.copy_(snap[1])
+            self.arena.refresh_bf16()
+            self.refresh_transposed()
+            del snap
+            torch.cuda.synchronize()
         self._pool = torch.cuda.graph_pool_handle()
         self._pool_branch = torch.cuda.graph_pool_handle()
         self._pool_opt = torch.cuda.graph_pool_handle()
@@ -342,7 +374,7 @@ class DetectorBase:
         if self.dist is not None and self._seen_buckets:
             # buckets seen in the eager warm-up: their transpose tables are built here, outside any capture
             self.opt_stream = torch.cuda.Stream()
-            self._cap_opt = (self.lr_dev, 0.9, 1e-4)
+            self._cap_opt = (self.lr_dev,) + hyper
             for lo_hi in sorted(self._seen_buckets):
                 self._transpose_table(*lo_hi)
         side = torch.cuda.Stream()
@@ -350,11 +382,11 @@ class DetectorBase:
         with torch.cuda.stream(side):
             self._cap = True
             self._seg_begin()
-            self._upd, self._upd_done = ((self.lr_dev, 0.9, 1e-4) if self.dist is None else None), []
+            self._upd, self._upd_done = (((self.lr_dev,) + hyper) if self.dist is None else None), []
             losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
                                            gt_masks=self.static_masks)
             self._upd = None
-            self.optimizer_step(self.lr_dev)
+            self.optimizer_step(self.lr_dev, hyper[0], hyper[1])
             self._seg_end()
             if self._final_join_opt:
                 self.segments.append(("join_opt",))

@@ -19,6 +19,18 @@ import torch
 from ...ops import dense
 
 
+def cached_buf(bufs, key, shape, dtype, device, zero=False):
+    """Activation / gradient buffer cache of a model part, keyed by (name, shape, dtype): a call at another shape
+    (inference with 1000 rois per image after training with 512) gets buffers of its own and never frees the ones a
+    captured hipGraph holds by address."""
+    k = (key, tuple(shape), dtype)
+    b = bufs.get(k)
+    if b is None:
+        b = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=device)
+        bufs[k] = b
+    return b
+
+
 class Workspace:
     """One caller-owned scratch buffer shared by every wgrad call (the C-ABI never allocates).
 
@@ -30,6 +42,7 @@ class Workspace:
         self.device = device
         self.need = 0
         self.buf = None
+        self._retired = []
         self.side = None
         # grouped mode: backward_weight() calls are recorded and issued together at flush() (one launch pair per
         # group -- a ResNet stage, the FPN, a head -- instead of two launches per layer)
@@ -96,6 +109,7 @@ class Workspace:
             plan = dense.GroupedWgrad(calls, self.device)
             self.plans[key] = plan
             if self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
+                self._retired.append(self.gbuf)
                 self.gbuf = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device=self.device)
         ctx = self.fork()
         with (ctx if ctx is not None else contextlib.nullcontext()):
@@ -129,6 +143,7 @@ class Workspace:
 
     def get(self):
         if self.buf is None or self.buf.numel() < self.need:
+            self._retired.append(self.buf)     # a captured step may hold the old one by address: never freed
             self.buf = torch.empty((self.need,), dtype=torch.uint8, device=self.device)
         return self.buf
 
@@ -177,7 +192,7 @@ class ConvLayer:
     """
 
     def __init__(self, name, cin, cout, k, stride=1, pad=None, bias=True, trainable=True, arena=None, ws=None,
-                 device="cuda", gen=None, init_std=None, zero_init=False, train_bias=True):
+                 device="cuda", gen=None, init_std=None, zero_init=False, train_bias=True, cout_real=None):
         self.name, self.cin, self.cout, self.k, self.stride = name, cin, cout, k, stride
         self.pad = (k // 2) if pad is None else pad
         self.trainable = trainable
@@ -185,6 +200,11 @@ class ConvLayer:
         self.has_bias = bias
         std = init_std if init_std is not None else math.sqrt(2.0 / (k * k * cin))   # He-normal
         w0 = torch.zeros((cout, k, k, cin)) if zero_init else torch.randn((cout, k, k, cin), generator=gen) * std
+        # output channels past cout_real are alignment padding (fused / padded head outputs): zero filters and zero
+        # biases, and every loss kernel writes zero gradients there, so they stay exactly zero through training
+        self.cout_real = cout if cout_real is None else cout_real
+        if self.cout_real < cout:
+            w0[self.cout_real:] = 0
         self._w0 = w0
         self.train_bias = bias and trainable and train_bias
         self.frozen_bias = None

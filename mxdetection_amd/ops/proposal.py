@@ -18,6 +18,7 @@ class PyramidProposal:
         self.A = self.base[0].shape[0]
         self.pre, self.post, self.thresh, self.min_size = pre_nms_top_n, post_nms_top_n, nms_thresh, min_size
         self._ws = None
+        self._retired = []
 
     def _desc(self, cls, reg, layout):
         """cls[l]/reg[l]: 'nhwc_fused' -> one tensor [N,H,W,Cpad] (logits ch 0..A-1, deltas A..5A-1);
@@ -50,6 +51,7 @@ class PyramidProposal:
         dev = im_info.device
         need = lib.mxdet_proposal_workspace_bytes(C.byref(d), N, self.pre)
         if self._ws is None or self._ws.numel() < need:
+            self._retired.append(self._ws)     # a captured step may hold the old one by address: never freed
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         if out is None:
             rois = torch.empty((N, self.post, 5), dtype=torch.float32, device=dev)

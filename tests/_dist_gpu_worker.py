@@ -16,7 +16,10 @@ def main():
     import torch.distributed as dist
     from test_gpu_model import _inputs
     from mxdetection_amd.models import FasterRCNN
-    dist.init_process_group(os.environ.get("MXDET_TEST_BACKEND", "gloo"), init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    backend = os.environ.get("MXDET_TEST_BACKEND", "gloo")
+    if backend == "nccl":                      # RCCL wants one device per rank
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     N, H, W = 2, 256, 320
     m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
     m.enable_wgrad_stream()
@@ -27,7 +30,8 @@ def main():
     m.arena.refresh_bf16()
     m.refresh_transposed()
     batch = _inputs(N, H, W, seed=10 + rank)
-    m.capture(*batch, lr=0.001, image_offset=rank * N, warmup=1)      # the warm-up step is training step 0 (eager)
+    m.train_step(*batch, step=0, image_offset=rank * N, lr=0.001)     # training step 0, eager (bucketed all-reduce)
+    m.capture(*batch, lr=0.001, image_offset=rank * N, warmup=1)      # the capture's own warm-up leaves the weights alone
     losses = torch.cat(m.replay(*batch, 1)).clone()                   # step 1 from the captured graphs
     torch.cuda.synchronize()
     w = m.arena.w.detach().cpu().numpy()

@@ -197,3 +197,19 @@ def test_voc_roidb():
     finally:
         os.remove(lst)
     assert len(VOC_CLASSES) == 20
+
+
+def test_epoch_order_small_and_skewed_datasets():
+    """A group (or the whole dataset) smaller than the padding it needs: the fill wraps cyclically."""
+    roidb = [{"width": 640, "height": 480}] * 40 + [{"width": 480, "height": 640}] * 3
+    o = epoch_order(roidb, 16, 0, seed=1)
+    assert o.size % 16 == 0 and set(o.tolist()) == set(range(43))
+    rows = o.reshape(-1, 16)
+    horz = np.array([r["width"] >= r["height"] for r in roidb])
+    assert all(len(set(horz[r].tolist())) == 1 for r in rows)              # no batch mixes the two groups
+    tiny = [{"width": 640, "height": 480}] * 5
+    for grouping in (True, False):
+        o = epoch_order(tiny, 16, 0, seed=1, aspect_grouping=grouping)
+        assert o.size == 16 and set(o.tolist()) == set(range(5))
+    o = epoch_order(tiny, 16, 0, shuffle=False)
+    assert o.tolist() == [i % 5 for i in range(16)]

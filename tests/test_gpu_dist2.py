@@ -25,7 +25,11 @@ def test_two_ranks_match_hand_averaged_reference(hip, tmp_path):
     port = s.getsockname()[1]
     s.close()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # two visible devices: the exchange goes over RCCL, one rank per device; one device: gloo on CUDA tensors
+    # (RCCL refuses two ranks on one device), i.e. "RCCL N>1 unverified" on such a box
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    print("exchange backend:", backend)
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MXDET_TEST_BACKEND=backend)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(r), "2", str(port), outs[r]],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     logs = []

@@ -108,7 +108,7 @@ def test_gradient_exchange_path_matches_single_gpu_step(hip):
         if parallel:
             m.enable_data_parallel(1)
         w0 = m.arena.w.clone()
-        m.capture(image, gt, im_info, lr=lr, image_offset=0, warmup=1)   # the warm-up step is a training step too
+        m.capture(image, gt, im_info, lr=lr, image_offset=0, warmup=1)   # the warm-up leaves weights / momentum alone
         losses = torch.cat(m.replay(image, gt, im_info, 1)).clone()
         torch.cuda.synchronize()
         return w0, m.arena.w.clone(), losses, m.arena.wb.float().clone()
@@ -218,3 +218,76 @@ def test_fused_backward_takes_the_same_step(hip):
     l1, w1, m = run(True)
     assert m.ws.flush_plans and any(p is not None for p in m.ws.flush_plans)
     assert torch.equal(l0, l1) and torch.equal(w0, w1)
+
+
+def test_graph_replay_honours_momentum_and_wd(hip):
+    """capture(momentum=, wd=) bakes the caller's hyper-parameters into the captured update, and its warm-up leaves the
+    weights alone: two replayed steps equal two eager train_step()s with the same non-default hyper-parameters."""
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    N, H, W = 2, 256, 320
+    image, gt, im_info = _inputs(N, H, W, seed=6)
+    lr, mom, wd = 0.001, 0.5, 1e-2
+
+    def build():
+        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+        m.enable_wgrad_stream()
+        m.enable_branch_stream()
+        m.enable_grouped_wgrad()
+        return m
+    e = build()
+    w0 = e.arena.w.clone()
+    for s in range(2):
+        e.train_step(image, gt, im_info, step=s, lr=lr, momentum=mom, wd=wd)
+    torch.cuda.synchronize()
+    g = build()
+    g.capture(image, gt, im_info, lr=lr, momentum=mom, wd=wd)
+    torch.cuda.synchronize()
+    assert torch.equal(g.arena.w, w0) and float(g.arena.m.abs().max()) == 0.0      # the warm-up trained nothing
+    for s in range(2):
+        g.replay(image, gt, im_info, s)
+    torch.cuda.synchronize()
+    moved = float((e.arena.w - w0).abs().max())
+    assert moved > 0
+    assert float((e.arena.w - g.arena.w).abs().max()) <= 1e-3 * moved
+    assert float((e.arena.m - g.arena.m).abs().max()) <= 1e-3 * float(e.arena.m.abs().max())
+    # and the defaults really are different: same two steps with momentum 0.9 / wd 1e-4 land elsewhere
+    d = build()
+    for s in range(2):
+        d.train_step(image, gt, im_info, step=s, lr=lr)
+    torch.cuda.synchronize()
+    assert float((d.arena.w - e.arena.w).abs().max()) > 10 * float((e.arena.w - g.arena.w).abs().max()) + 1e-12
+
+
+def test_predict_between_replays_leaves_the_captured_step_intact(hip):
+    """Inference on a captured model (per-epoch evaluation) runs the heads at another roi count: its buffers are its own,
+    the captured graphs' buffers stay put, and a replay afterwards takes exactly the step it would have taken."""
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    N, H, W = 2, 256, 320
+    image, gt, im_info = _inputs(N, H, W, seed=8)
+
+    def run(with_predict):
+        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+        m.enable_wgrad_stream()
+        m.enable_branch_stream()
+        m.enable_grouped_wgrad()
+        m.capture(image, gt, im_info, lr=0.001)
+        m.replay(image, gt, im_info, 0)
+        if with_predict:
+            dets, num = m.predict(image, im_info)
+            torch.cuda.synchronize()
+            assert dets.shape[0] == N and int(num.min()) >= 0
+            junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]   # recycle freed memory, if any
+            del junk
+        losses = torch.cat(m.replay(image, gt, im_info, 1)).clone()
+        torch.cuda.synchronize()
+        return m.arena.w.clone(), losses
+    w_a, l_a = run(False)
+    w_b, l_b = run(True)
+    assert torch.equal(l_a, l_b) and torch.equal(w_a, w_b)
+    # a call at another IMAGE shape would re-plan the pyramid buffers the graphs hold: refused
+    m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+    m.capture(image, gt, im_info, lr=0.001)
+    with pytest.raises(RuntimeError, match="captured training step"):
+        m.predict(image[:, :, :192, :256].contiguous(), im_info)

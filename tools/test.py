@@ -14,6 +14,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", default=None)
     ap.add_argument("--params", default="")
+    ap.add_argument("--random-init", action="store_true",
+                    help="evaluate the randomly initialised model (plumbing checks only); without it --params is required")
     ap.add_argument("--max-images", type=int, default=0)
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args()
@@ -24,7 +26,9 @@ def main():
     cfg = load_config(args.cfg, list(args.overrides) + ["TRAIN.flip=false"])
     model = build_detector(cfg)
     if args.params:
-        model.load_checkpoint(args.params, strict=False)
+        model.load_checkpoint(args.params, strict=True)      # raises on any parameter the file lacks
+    elif not args.random_init:
+        sys.exit("tools/test.py: no --params given (use --random-init to evaluate untrained weights on purpose)")
     segm = cfg.network.type == "mask_rcnn"
     roidb, _, loader = build_loader(cfg, train=False, with_masks=segm)
     te = cfg.TEST

@@ -60,7 +60,7 @@ def main():
             lr = sched(it)
             img, gt, info, mk = batch["image"], batch["gt_boxes"], batch["im_info"], batch.get("gt_masks")
             if use_graph and not captured:
-                model.capture(img, gt, info, lr=lr, image_offset=off, gt_masks=mk)
+                model.capture(img, gt, info, lr=lr, image_offset=off, gt_masks=mk, momentum=tr.momentum, wd=tr.wd)
                 captured = True
             if use_graph:
                 losses = model.replay(img, gt, info, it, gt_masks=mk, lr=lr)
