@@ -267,9 +267,7 @@ def main():
         model.enable_fused_backward()
     if dist is not None:
         model.enable_data_parallel(world)
-        dist.broadcast(model.arena.w, 0)
-        model.arena.refresh_bf16()
-        model.refresh_transposed()
+        model.broadcast_parameters(0)
     # linear-scaling rule from lr 0.02 @ batch 16, at the warm-up start factor 1/3 (random-init weights, no BN)
     lr = 0.02 * (BATCH_PER_GPU * world) / 16.0 / 3.0
     batches = [synth_batch(rank, s, device) for s in range(4)]

@@ -33,6 +33,7 @@ extern "C" {
 #define MXDET_ESHAPE (-2)
 #define MXDET_EWORKSPACE (-3)
 #define MXDET_EHIP (-4)
+#define MXDET_ERCCL (-5)
 
 #define MXDET_DTYPE_F32 0
 #define MXDET_DTYPE_BF16 1
@@ -366,11 +367,6 @@ int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, 
 int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_reduce,
                                void* workspace, size_t workspace_bytes, size_t workspace_needed,
                                mxdet_stream_t stream);
-/* tuning / test hook: force the conv tile configuration on this thread (0 = built-in heuristic,
- * 1..8 = a specific tile/ring configuration, see conv.hip launch()) */
-int mxdet_debug_force_conv_cfg(int32_t cfg);
-/* Tuning hook: force the split-K factor of mxdet_conv2d_wgrad on the calling thread (0 = heuristic). */
-int mxdet_debug_force_wgrad_ksplit(int32_t ksplit);
 /* Fused backward launch: the data-gradient tiles of a planned conv group (kind 1, tile cfg 2 or 3; table, cfg and
  * grid from mxdet_conv2d_grouped_plan) and the weight-gradient tiles [w_block_begin, w_block_end) of a planned wgrad
  * group in ONE grid, so that both kinds of workgroups share the CUs (small-map dgrad launches leave half the chip idle
@@ -384,10 +380,6 @@ int mxdet_conv2d_wgrad_grouped_item_blocks(const void* table_host, int32_t n, in
 int mxdet_conv2d_wgrad_grouped_from(const void* table_dev, int32_t n, int32_t block_begin, int32_t grid_wgrad,
                                     int32_t grid_reduce, void* workspace, size_t workspace_bytes,
                                     size_t workspace_needed, mxdet_stream_t stream);
-/* tuning hook: issue a grouped weight-gradient launch in chunks of `workgroups` (0 = one launch) */
-int mxdet_debug_wgrad_group_chunk(int32_t workgroups);
-/* tuning hook: run grouped weight-gradient launches as a persistent grid of `workgroups` (rounded up to 8; 0 = off) */
-int mxdet_debug_wgrad_group_persist(int32_t workgroups);
 /* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);
@@ -451,7 +443,6 @@ typedef struct {
   double inv_scale;       /* 1 / scale */
 } mxdet_image_desc_t;
 #define MXDET_PREPROCESS_MAX_BATCH 64
-int mxdet_debug_preprocess_direct(int32_t on);   /* test hook: 1 = always use the direct-gather kernel (wide-frame path) */
 int mxdet_image_preprocess(const mxdet_image_desc_t* images /* host array */, int32_t N, int32_t Hp, int32_t Wp,
                            const float* mean3 /* host */, const float* std3 /* host */, int32_t swap_rb,
                            uint16_t* out, mxdet_stream_t stream);
@@ -495,6 +486,35 @@ int mxdet_sgd_momentum_update(float* w, const float* grad, float* mom, uint16_t*
 int mxdet_sgd_momentum_update_sched(float* w, const float* grad, float* mom, uint16_t* w_bf16, int64_t n,
                                     const float* lr_dev, float momentum, float wd, float rescale,
                                     mxdet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * data-parallel gradient exchange (MXNet role: kvstore push/pull, /root/reference/README.md:37; SURVEY.md
+ * sections 8a10, 8b, 8e). One process per GPU; the only exchange of the hot path is the fp32 sum of contiguous slices
+ * ("buckets") of the flat gradient arena, over RCCL (xGMI). `mxdet_comm_t` is the one explicit handle of the library:
+ * an RCCL communicator + a side stream of its own + a ring of events, created and destroyed by the caller. The library
+ * resolves RCCL at run time (the copy already mapped into the process, else librccl.so.1); without it every entry
+ * below returns MXDET_ERCCL.
+ *
+ *   rank 0: mxdet_comm_unique_id(id) -> the caller hands the MXDET_COMM_ID_BYTES bytes to every rank by any channel
+ *   every rank, with its device current: mxdet_comm_create(id, world, rank, &comm)           (collective)
+ *   per bucket, as soon as backward has finalised it: mxdet_allreduce_bucket(comm, g + lo, hi - lo, s, &ticket)
+ *       the sum is ordered behind everything enqueued on stream `s` so far and runs on the communicator's side
+ *       stream: `s` itself does not wait (the rest of backward overlaps the exchange);
+ *   before the bucket is consumed: mxdet_comm_wait(comm, ticket, t) makes stream `t` wait for that bucket's sum
+ *       (ticket -1: for every bucket issued so far).
+ * Sums are fp32, in place, in RCCL's fixed order for the communicator (run-to-run identical); the 1/world average is
+ * the optimizer's `rescale`. At most MXDET_COMM_MAX_INFLIGHT buckets may be un-waited at a time. */
+typedef struct mxdet_comm mxdet_comm_t;
+#define MXDET_COMM_ID_BYTES 128
+#define MXDET_COMM_MAX_INFLIGHT 64
+int mxdet_comm_unique_id(uint8_t* id /* host, MXDET_COMM_ID_BYTES */);
+int mxdet_comm_create(const uint8_t* id, int32_t world, int32_t rank, mxdet_comm_t** comm_out);
+int mxdet_comm_destroy(mxdet_comm_t* comm);
+int mxdet_allreduce_bucket(mxdet_comm_t* comm, float* grad, int64_t count, mxdet_stream_t stream,
+                           int32_t* ticket_out);
+int mxdet_comm_wait(mxdet_comm_t* comm, int32_t ticket, mxdet_stream_t stream);
+/* replicate `bytes` bytes of `buf` from rank `root` (initial weights); ordered on `stream` itself */
+int mxdet_comm_broadcast(mxdet_comm_t* comm, void* buf, size_t bytes, int32_t root, mxdet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,40 @@
+/*
+ * mxdet_debug.h -- tuning and test hooks of libmxdet_hip.so. NOT part of the drop-in boundary (include/mxdet.h):
+ * nothing a reference-side binding calls is declared here. Unlike the boundary's entries, the hooks set state that
+ * later calls read (per calling thread where noted, otherwise library-wide): sweeps and tests only.
+ */
+#ifndef MXDET_DEBUG_H_
+#define MXDET_DEBUG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* force the conv tile configuration on this thread (0 = built-in heuristic, else a case of conv.hip launch()) */
+int mxdet_debug_force_conv_cfg(int32_t cfg);
+/* force the split-K factor of mxdet_conv2d_wgrad on the calling thread (0 = heuristic) */
+int mxdet_debug_force_wgrad_ksplit(int32_t ksplit);
+/* issue a grouped weight-gradient launch in chunks of `workgroups` (0 = one launch); library-wide */
+int mxdet_debug_wgrad_group_chunk(int32_t workgroups);
+/* run grouped weight-gradient launches as a persistent grid of `workgroups` (rounded up to 8; 0 = off); library-wide */
+int mxdet_debug_wgrad_group_persist(int32_t workgroups);
+/* 1 = always use the direct-gather preprocess kernel (the wide-frame path); library-wide */
+int mxdet_debug_preprocess_direct(int32_t on);
+
+/* Plan-time thresholds of the tile / split heuristics (library-wide; value < 0 restores the built-in default).
+ * The library itself never reads the environment: tools that sweep these call the hook. */
+#define MXDET_TUNE_T64 0          /* conv: 64-row tiles from this many tiles on (default 400) */
+#define MXDET_TUNE_T128 1         /* conv: 256x256 (+ tail) tiles from this many 128x128 tiles on (default 1536) */
+#define MXDET_TUNE_PAR64 2        /* stride-2 dgrad: 64x128 tiles from this many tiles on (default 1600) */
+#define MXDET_TUNE_WG_TARGET 3    /* grouped wgrad: workgroups per group aimed for (default 3072) */
+#define MXDET_TUNE_WG_MINSTEPS 4  /* grouped wgrad: fewest 32-pixel steps per workgroup (default 64) */
+#define MXDET_TUNE_WG_MAXSTEPS 5  /* grouped wgrad: most steps per workgroup (default 128) */
+#define MXDET_TUNE_COUNT 6
+int mxdet_debug_set_tuning(int32_t which, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXDET_DEBUG_H_ */

@@ -150,7 +150,19 @@ SIGNATURES = {
     "mxdet_nhwc_to_nchw_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_sgd_momentum_update": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "mxdet_sgd_momentum_update_sched": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_f32, c_f32, c_vp]),
+    "mxdet_comm_unique_id": (c_i32, [c_vp]),
+    "mxdet_comm_create": (c_i32, [c_vp, c_i32, c_i32, P(c_vp)]),
+    "mxdet_comm_destroy": (c_i32, [c_vp]),
+    "mxdet_allreduce_bucket": (c_i32, [c_vp, c_vp, c_i64, c_vp, P(c_i32)]),
+    "mxdet_comm_wait": (c_i32, [c_vp, c_i32, c_vp]),
+    "mxdet_comm_broadcast": (c_i32, [c_vp, c_vp, c_sz, c_i32, c_vp]),
+    "mxdet_debug_set_tuning": (c_i32, [c_i32, c_i64]),
 }
+
+# entries declared in include/mxdet_debug.h (tuning / test hooks, not part of the drop-in boundary)
+DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
+                 "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
+TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5}
 
 _lib = None
 
@@ -180,6 +192,12 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # sweep tooling (tools/tune_sweep.sh): MXDET_TUNE_<KEY>=value is read HERE, by the Python host side, and handed to
+    # the debug hook; the library itself never reads the environment
+    for key, idx in TUNING_KEYS.items():
+        v = os.environ.get("MXDET_TUNE_" + key)
+        if v:
+            lib.mxdet_debug_set_tuning(idx, int(v))
     return lib
 
 

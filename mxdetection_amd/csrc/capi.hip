@@ -15,7 +15,19 @@ void set_error(const char* fmt, ...) {
 }
 void clear_error() { g_err[0] = 0; }
 
+// plan-time thresholds, index = MXDET_TUNE_* (include/mxdet_debug.h)
+static const long long kTuneDefault[MXDET_TUNE_COUNT] = {400, 1536, 1600, 3072, 64, 128};
+static long long g_tune[MXDET_TUNE_COUNT] = {400, 1536, 1600, 3072, 64, 128};
+long long tuning(int which) { return g_tune[which]; }
+
 }  // namespace mxdet
 
 extern "C" const char* mxdet_last_error(void) { return mxdet::g_err; }
-extern "C" const char* mxdet_version(void) { return "mxdet-hip 0.1 gfx950"; }
+extern "C" const char* mxdet_version(void) { return "mxdet-hip 0.2 gfx950"; }
+
+extern "C" int mxdet_debug_set_tuning(int32_t which, int64_t value) {
+  mxdet::clear_error();
+  MXDET_REQUIRE(which >= 0 && which < MXDET_TUNE_COUNT, MXDET_EINVAL, "debug_set_tuning: unknown key %d", which);
+  mxdet::g_tune[which] = value < 0 ? mxdet::kTuneDefault[which] : (long long)value;
+  return MXDET_OK;
+}

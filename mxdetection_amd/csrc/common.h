@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/mxdet.h"
+#include "../../include/mxdet_debug.h"
 #include "../../include/mxdet_math.h"
 
 namespace mxdet {
@@ -30,6 +31,9 @@ inline int check_launch(const char* what) {
       return (code);                    \
     }                                   \
   } while (0)
+
+// plan-time thresholds (mxdet_debug_set_tuning; defaults in capi.hip). The library never reads the environment.
+long long tuning(int which);
 
 static inline hipStream_t as_stream(mxdet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

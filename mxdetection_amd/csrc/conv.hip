@@ -610,15 +610,11 @@ fused_bwd_kernel(const ConvG* __restrict__ ctable, int cn, int cgrid, int cgrid_
 
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
 
-// Tile-choice thresholds. Environment overrides exist because these only tune correctly on whole-step A/B runs (a layer
-// replayed alone keeps its filter in L2 and owns the chip): MXDET_TUNE_T64, _T128, _PAR64.
-static int tune_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-static int thr_t64() { static const int v = tune_int("MXDET_TUNE_T64", 400); return v; }
-static int thr_t128() { static const int v = tune_int("MXDET_TUNE_T128", 1536); return v; }
-static int thr_par64() { static const int v = tune_int("MXDET_TUNE_PAR64", 1600); return v; }
+// Tile-choice thresholds (mxdet_debug_set_tuning overrides them for sweeps: they only tune correctly on whole-step
+// A/B runs -- a layer replayed alone keeps its filter in L2 and owns the chip).
+static int thr_t64() { return (int)tuning(MXDET_TUNE_T64); }
+static int thr_t128() { return (int)tuning(MXDET_TUNE_T128); }
+static int thr_par64() { return (int)tuning(MXDET_TUNE_PAR64); }
 
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
 static int launch_cfg(ConvP& p, hipStream_t s) {

@@ -403,10 +403,10 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
     const int steps = ceil_div(p.M, kWgradBKP);
     // aim for ~3000 workgroups over the group (3 rounds of the 1024 resident ones)
     // measured sweep (profiles/r01_h_grouped_wgrad_sweep.txt): ~3072 workgroups per group, 64..128 steps each
-    // (environment overrides for whole-step tuning, e.g. shorter workgroups for the fused backward launch)
-    static const long long target = getenv("MXDET_TUNE_WG_TARGET") ? atoll(getenv("MXDET_TUNE_WG_TARGET")) : 3072;
-    static const int min_steps = getenv("MXDET_TUNE_WG_MINSTEPS") ? atoi(getenv("MXDET_TUNE_WG_MINSTEPS")) : 64;
-    static const int max_steps = getenv("MXDET_TUNE_WG_MAXSTEPS") ? atoi(getenv("MXDET_TUNE_WG_MAXSTEPS")) : 128;
+    // (mxdet_debug_set_tuning overrides for whole-step sweeps, e.g. shorter workgroups for the fused backward launch)
+    const long long target = tuning(MXDET_TUNE_WG_TARGET);
+    const int min_steps = (int)tuning(MXDET_TUNE_WG_MINSTEPS);
+    const int max_steps = (int)tuning(MXDET_TUNE_WG_MAXSTEPS);
     long long want = tiles_total > 0 ? (target + tiles_total - 1) / tiles_total : 1;
     int ks = (int)want;
     const int max_ks = steps / min_steps > 0 ? steps / min_steps : 1, min_ks = ceil_div(steps, max_steps);

@@ -6,7 +6,7 @@ import warnings
 
 import torch
 
-from .dp import BucketReducer
+from .dp import BucketReducer, make_comm
 from .layers import ParamArena, Workspace
 
 
@@ -17,6 +17,7 @@ class DetectorBase:
         self.ws = Workspace(device)
         self.planned = None
         self.dist = None
+        self.comm = None
         self.world = 1
         self.segments = None
         self._cap = False
@@ -189,10 +190,22 @@ class DetectorBase:
         import torch.distributed as dist
         self.dist = dist
         self.world = world_size
-        self.reducer = BucketReducer(self.arena.g, dist)
+        # RCCL process group: the exchange goes through the library's own collective (mxdet_allreduce_bucket);
+        # gloo (CPU tests, two ranks on one GPU): through torch.distributed
+        self.comm = make_comm(dist)
+        self.reducer = BucketReducer(self.arena.g, dist, comm=self.comm)
         # with a gradient exchange the buckets stay fine (five: every all-reduce but the last overlaps the rest of
         # backward); their weight gradients run as side-stream graphs (_reduce), so fine buckets cost nothing here
         self.bucket_merge = os.environ.get("MXDET_TUNE_BUCKETS", "")
+
+    def broadcast_parameters(self, root=0):
+        """Replicate rank `root`'s master weights (and refresh the bf16 / transposed working copies)."""
+        if getattr(self, "comm", None) is not None:
+            self.comm.broadcast(self.arena.w, root)
+        else:
+            self.dist.broadcast(self.arena.w, root)
+        self.arena.refresh_bf16()
+        self.refresh_transposed()
 
     def _bucket_here(self, point):
         """Reduce points of backward, in order: 0 heads, 1 FPN, 2 layer4, 3 layer3 (layer2 always closes the last

@@ -38,9 +38,7 @@ def main():
         model.load_checkpoint(tr.resume)
     if dist is not None:
         model.enable_data_parallel(world)
-        dist.broadcast(model.arena.w, 0)
-        model.arena.refresh_bf16()
-        model.refresh_transposed()
+        model.broadcast_parameters(0)
     roidb, _, loader = build_loader(cfg, rank=rank, world=world, train=True)
     iters_per_epoch = len(loader)
     base_lr = scaled_lr(tr.lr, tr.batch_images * world) if tr.lr_reference_batch == 16 else tr.lr * tr.batch_images * world / tr.lr_reference_batch
