@@ -348,6 +348,10 @@ class DetectorBase:
                 warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         if not empty:
             self.segments.append(self._cur_graph)
+        else:
+            # kept alive, never replayed: destroying the only graph of a memory pool releases the pool, and the next
+            # capture_begin on it trips an allocator assertion
+            self._empty_graphs.append(self._cur_graph)
         self._cur_graph = None
 
     # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
@@ -381,6 +385,7 @@ class DetectorBase:
         self._pool_opt = torch.cuda.graph_pool_handle()
         self._pool_w = torch.cuda.graph_pool_handle()
         self.segments = []
+        self._empty_graphs = []
         self._buckets = []
         self._cap_opt = None
         self._final_join_opt = False

@@ -197,7 +197,7 @@ class RefModel:
             v.grad = None
         total.backward()
         grads = {k: (v.grad.clone() if v.grad is not None else None) for k, v in self.p.items()}
-        return {"losses": [float(rpn_cls), float(rpn_reg), float(rcnn_cls), float(rcnn_reg)], "grads": grads,
+        return {"losses": [float(v.detach()) for v in (rpn_cls, rpn_reg, rcnn_cls, rcnn_reg)], "grads": grads,
                 "rois": rois, "num_rois": num, "sampled_rois": srois, "labels": slab, "heads": hs}
 
 

@@ -1,0 +1,183 @@
+"""Oracle parity at the BASELINE.json workload itself (config 2: N = 2 images of 3x800x1333 padded to 1344, 268,569
+anchors per image, pre/post-NMS 2000 per level / per image, 512 sampled rois per image, 256-channel pyramid):
+
+  HIP RPN head outputs -> oracle.proposal        == HIP proposals            (bits of boxes / scores, indices, counts)
+  HIP proposals + GT   -> oracle.proposal_target == HIP sampled rois / labels / targets / weights
+  GT + anchor grid     -> oracle.anchor_target   == HIP anchor labels / targets (268,569 x 2)
+  HIP pyramid + rois   -> oracle.roi_align       == HIP pooled features (1,024 rois x 256 channels x 7 x 7, bf16 bits)
+  RetinaNet-R101 heads -> oracle.retina_detect   == HIP test-time detection over 201,600 x 80 (anchor, class) logits
+
+The smaller tests (tests/test_gpu_detection.py) cover edge cases (ties, empty images, clipped boxes); these run the
+shapes the benchmark is quoted on: 50 selection chunks per P2 list instead of 3, the finish kernel's tie path near its
+4096-key limit, the sampling compaction at full anchor count. The oracle is this repo's CPU restatement -- the
+reference holds no code or vectors ("parity unpinned")."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STRIDES = [4, 8, 16, 32, 64]
+
+
+def _bits(t):
+    import torch
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.fixture(scope="module")
+def step(hip):
+    """One eager forward_backward of Faster R-CNN R50-FPN at the benchmark shape, on the benchmark's synthetic batch."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mxdetection_amd.models import FasterRCNN
+    m = FasterRCNN("cuda", depth=50, seed=7)
+    img, gt, info = bench.synth_batch(0, 1, "cuda")
+    STEP, OFF = 3, 4
+    m.forward_backward(img, gt, info, step=STEP, image_offset=OFF)
+    torch.cuda.synchronize()
+    return m, img, gt, info, STEP, OFF
+
+
+def test_full_size_proposals_and_sampling_bit_exact(step, oracle):
+    m, img, gt, info, STEP, OFF = step
+    N, A = 2, 3
+    gt_np, info_np = gt.cpu().numpy(), info.cpu().numpy()
+    hs = [h.float().cpu().numpy() for h in m.rpn_head.h]
+    shapes = [(h.shape[1], h.shape[2]) for h in hs]
+    assert shapes[0] == (200, 336) and sum(s[0] * s[1] * A for s in shapes) == 268569
+    sc = [h[..., :A].reshape(N, -1) for h in hs]
+    dl = [h[..., A:5 * A].reshape(N, -1, 4) for h in hs]
+    base = [oracle.base_anchors(s) for s in STRIDES]
+    rois, rs, ra, num = oracle.proposal(sc, dl, base, [s[0] for s in shapes], [s[1] for s in shapes], STRIDES, info_np,
+                                        2000, 2000, 0.7, 0.0)
+    g_rois, g_rs, g_ra, g_num = [t.cpu().numpy() for t in m.rpn_head.get_proposals(info)]
+    assert np.array_equal(g_num, num) and int(num.min()) > 500          # a real workload, not a degenerate one
+    assert np.array_equal(g_ra, ra)                                     # kept anchor indices, in order
+    assert np.array_equal(g_rois.view(np.uint32), rois.view(np.uint32))
+    assert np.array_equal(g_rs.view(np.uint32), rs.view(np.uint32))
+    # proposal-target: 2000 + G candidates -> 512 per image
+    srois, slab, stgt, swgt, smat, nfg = oracle.proposal_target(rois, num, gt_np, 512, 0.25, 0.5, 0.5, 0.0, 81, False,
+                                                                (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2), 99, STEP, OFF)
+    bh = m.bbox_head
+    assert np.array_equal(bh.rois.cpu().numpy().view(np.uint32), srois.view(np.uint32))
+    assert np.array_equal(bh.labels.cpu().numpy().reshape(slab.shape), slab)
+    assert np.array_equal(bh.num_fg.cpu().numpy(), nfg) and int(nfg.min()) > 0
+    assert np.array_equal(bh.tgt.cpu().numpy().reshape(stgt.shape).view(np.uint32), stgt.view(np.uint32))
+    assert np.array_equal(bh.wgt.cpu().numpy().reshape(swgt.shape).view(np.uint32), swgt.view(np.uint32))
+    fg = slab > 0
+    assert np.array_equal(bh.matched.cpu().numpy().reshape(smat.shape)[fg], smat[fg])
+
+
+def test_full_size_anchor_targets_bit_exact(step, oracle):
+    m, img, gt, info, STEP, OFF = step
+    anchors = np.concatenate([oracle.grid_anchors(oracle.base_anchors(s), H, W, s)
+                              for s, (H, W) in zip(STRIDES, m.rpn_head.level_shapes)])
+    assert anchors.shape == (268569, 4)
+    assert np.array_equal(m.rpn_head.anchors.cpu().numpy().view(np.uint32), anchors.view(np.uint32))
+    rh = m.rpn_head
+    w_lab, w_mg, w_tg, _ = oracle.anchor_target(anchors, gt.cpu().numpy(), info.cpu().numpy(), rh.fg_thresh, rh.bg_thresh,
+                                                0.0, rh.batch_size, rh.fg_fraction, rh.seed, STEP, OFF)
+    lab, mg, tg, _ = [t.cpu().numpy() for t in rh.at_out]
+    assert np.array_equal(lab, w_lab)
+    assert all((w_lab[n] >= 0).sum() == 256 and 0 < (w_lab[n] == 1).sum() <= 128 for n in range(2))
+    fg = w_lab == 1
+    assert np.array_equal(mg[fg], w_mg[fg])
+    assert np.array_equal(tg.view(np.uint32), w_tg.view(np.uint32))
+
+
+def test_full_size_roi_align_bit_exact(step, oracle):
+    m, img, gt, info, STEP, OFF = step
+    ex = m.roi_extractor
+    feats = [_bits(f) for f in ex.feats]
+    assert feats[0].shape == (2, 200, 336, 256) and len(feats) == 4
+    rois = ex.rois.cpu().numpy().reshape(-1, 5)
+    levels = ex.levels.cpu().numpy()
+    assert rois.shape == (1024, 5)
+    assert np.array_equal(levels, oracle.fpn_level(rois))
+    want = oracle.roi_align(feats, ex.scales, rois, levels, 7, 7, 2)
+    got = _bits(ex.out)
+    assert got.shape == (1024, 7, 7, 256)
+    assert np.array_equal(got, want)
+
+
+def test_full_size_retina_detect_bit_exact(hip, oracle):
+    """RetinaNet R101-FPN head outputs at 800x1344 (P3 = 100x168: 151,200 anchors x 80 classes on the finest level,
+    201,600 anchors in all) through mxdet_retina_detect vs the oracle's top-k / decode / per-class NMS."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mxdetection_amd.core.evaluation import RetinaDetect
+    from mxdetection_amd.models import RetinaNet
+    m = RetinaNet("cuda", depth=101, seed=7)
+    img, gt, info = bench.synth_batch(0, 2, "cuda")
+    N = 2
+    # random-init logits sit at the focal prior (p = 0.01 < the score threshold): lift them so that thousands of
+    # (anchor, class) pairs survive the threshold and the per-class NMS has real work
+    dets, num = m.predict(img, info, score_thresh=0.0005, nms_thresh=0.5, max_per_image=100)
+    torch.cuda.synchronize()
+    head = m.head
+    A, Cn = head.A, head.Cn
+    cls = [c.float().cpu().numpy() for c in head.co]
+    reg = [r.float().cpu().numpy() for r in head.bo]
+    shapes = [(c.shape[1], c.shape[2]) for c in cls]
+    assert shapes[0] == (100, 168) and sum(h * w * A for h, w in shapes) == 201600
+    cl = [c[..., :A * Cn].reshape(N, -1) for c in cls]
+    dl = [r[..., :A * 4].reshape(N, -1, 4) for r in reg]
+    base = [b.cpu().numpy() for b in head.base]
+    det = m._det
+    assert isinstance(det, RetinaDetect)
+    want, wnum = oracle.retina_detect(cl, dl, base, [s[0] for s in shapes], [s[1] for s in shapes], head.strides,
+                                      info.cpu().numpy(), Cn, det.pre_n, 0.0005, 0.5, 100)
+    assert np.array_equal(num.cpu().numpy(), wnum) and int(wnum.min()) > 10
+    assert np.array_equal(dets.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_full_size_exchange_schedule_over_rccl_world1(hip):
+    """The N > 1 schedule (graph segments cut at five buckets, side-stream weight-gradient graphs, per-bucket update
+    graphs, the exchange through mxdet_allreduce_bucket) at the benchmark shape, over RCCL at world size 1: it must take
+    the step the single-GPU schedule takes."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    from mxdetection_amd.models import FasterRCNN
+    img, gt, info = bench.synth_batch(0, 0, "cuda")
+    lr = 0.02 * 2 / 16.0 / 3.0
+
+    def one_step(parallel):
+        m = FasterRCNN("cuda", depth=50, seed=7)
+        m.enable_wgrad_stream()
+        m.enable_branch_stream()
+        m.enable_grouped_wgrad()
+        if parallel:
+            m.enable_data_parallel(1)
+            assert m.comm is not None                       # the C-ABI communicator, not torch.distributed
+        w0 = m.arena.w.clone()
+        m.capture(img, gt, info, lr=lr)
+        losses = torch.cat(m.replay(img, gt, info, 0)).clone()
+        torch.cuda.synchronize()
+        nb = len(m._buckets)
+        if parallel:
+            m.comm.close()
+        return w0, m.arena.w.clone(), losses, nb
+
+    w0, w_single, l_single, _ = one_step(False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        _, w_par, l_par, nb = one_step(True)
+    finally:
+        dist.destroy_process_group()
+    assert nb >= 4                                          # the exchange really was bucketed
+    moved = (w_single - w0).abs().max().item()
+    assert moved > 0
+    assert torch.equal(l_single, l_par)                     # the forward of step 0 sees identical weights
+    assert (w_single - w_par).abs().max().item() <= 1e-3 * moved
