@@ -363,9 +363,10 @@ typedef struct {
 } mxdet_wgrad_item_t;
 size_t mxdet_conv2d_wgrad_grouped_table_bytes(int32_t n);
 int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, void* table_host, size_t table_bytes,
-                                    size_t* workspace_bytes, int32_t* grid_wgrad, int32_t* grid_reduce);
-int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_reduce,
-                               void* workspace, size_t workspace_bytes, size_t workspace_needed,
+                                    size_t* workspace_bytes, int32_t* grid_wgrad, int32_t* grid_big,
+                                    int32_t* grid_reduce);
+int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
+                               int32_t grid_reduce, void* workspace, size_t workspace_bytes, size_t workspace_needed,
                                mxdet_stream_t stream);
 /* Fused backward launch: the data-gradient tiles of a planned conv group (kind 1, tile cfg 2 or 3; table, cfg and
  * grid from mxdet_conv2d_grouped_plan) and the weight-gradient tiles [w_block_begin, w_block_end) of a planned wgrad

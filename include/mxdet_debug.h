@@ -31,7 +31,12 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_WG_TARGET 3    /* grouped wgrad: workgroups per group aimed for (default 3072) */
 #define MXDET_TUNE_WG_MINSTEPS 4  /* grouped wgrad: fewest 32-pixel steps per workgroup (default 64) */
 #define MXDET_TUNE_WG_MAXSTEPS 5  /* grouped wgrad: most steps per workgroup (default 128) */
-#define MXDET_TUNE_COUNT 6
+#define MXDET_TUNE_WGB_ENABLE 6   /* grouped wgrad: 1 = items with Cout, Cin >= 256 use the 256x256-tile kernel (default 0:
+                                     measured 16 % faster on the P2-sized layers alone, 0.1-1 % slower on the whole step) */
+#define MXDET_TUNE_WGB_TARGET 7   /* ... workgroups of that kernel per group aimed for (default 512) */
+#define MXDET_TUNE_WGB_MINSTEPS 8 /* ... fewest 64-pixel steps per workgroup (default 16) */
+#define MXDET_TUNE_WGB_MINPX 9    /* ... only for items with at least this many output pixels (default 100000) */
+#define MXDET_TUNE_COUNT 10
 int mxdet_debug_set_tuning(int32_t which, int64_t value);
 
 #ifdef __cplusplus

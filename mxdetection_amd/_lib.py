@@ -126,8 +126,8 @@ SIGNATURES = {
     "mxdet_conv2d_grouped_plan": (c_i32, [P(ConvItemT), c_i32, c_i32, c_vp, c_sz, P(c_i32), P(c_i32)]),
     "mxdet_conv2d_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mxdet_conv2d_wgrad_grouped_table_bytes": (c_sz, [c_i32]),
-    "mxdet_conv2d_wgrad_grouped_plan": (c_i32, [P(WgradItemT), c_i32, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32)]),
-    "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
+    "mxdet_conv2d_wgrad_grouped_plan": (c_i32, [P(WgradItemT), c_i32, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32), P(c_i32)]),
+    "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_debug_force_wgrad_ksplit": (c_i32, [c_i32]),
     "mxdet_fused_dgrad_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -162,7 +162,8 @@ SIGNATURES = {
 # entries declared in include/mxdet_debug.h (tuning / test hooks, not part of the drop-in boundary)
 DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
                  "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
-TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5}
+TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "WGB_ENABLE": 6,
+               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9}
 
 _lib = None
 

@@ -38,6 +38,9 @@ long long tuning(int which);
 static inline hipStream_t as_stream(mxdet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int kWave = 64;
+// byte offset that is out of range for every buffer descriptor of the library (tensors are < 2^31 elements): an LDS-DMA
+// lane given this offset writes 16 zero bytes into its LDS slot (measured, tools/micro/dma_oob.hip)
+constexpr unsigned kDmaOob = 0xfffffff0u;
 
 template <typename T>
 __host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
@@ -59,6 +62,16 @@ static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
 }
 
 // ---- device helpers ----------------------------------------------------------------------------
+// raw buffer descriptor (stride 0, `bytes` records) over a tensor, built from provably wave-uniform words so that hipcc
+// keeps it in SGPRs (a descriptor it cannot prove uniform gets a waterfall loop around every buffer instruction)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }

@@ -51,9 +51,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-// 16 bytes of zeros that padding / out-of-range lanes of an LDS-DMA load read instead of the tensor
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -131,7 +128,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   // (HP: row 16j + (l>>2), 16-B slot l&3 of a 64-B half row; the swizzle uses two bits)
   const int lrow = HP ? lane >> 2 : lane >> 3, lslot = HP ? lane & 3 : lane & 7;
   constexpr int SWZ = HP ? 3 : 7;
-  const unsigned short* zero = (const unsigned short*)g_zero_page;
+  // LDS-DMA in the buffer form (descriptor in SGPRs + 32-bit byte offset per lane): a fifth of the per-wave issue cost
+  // of the 64-bit-address form (tools/micro/dma_rate.hip: 20 vs 116 cycles per 1-KiB piece), and a lane whose offset is
+  // out of range writes zeros into its LDS slot by itself (padding taps need no zero page and no pointer select)
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(p.x, 2u * (unsigned)(p.N * p.Hs * p.Ws) * (unsigned)p.C);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.w, 2u * (unsigned)p.Ncols * (unsigned)(p.KH * p.KW * p.C));
   const int ntaps = p.KH * p.KW;
   int a_off[GA];
   unsigned a_mask[GA];
@@ -185,13 +186,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   }
   const int Ktot = ntaps * p.C;
   const int KT = PAR ? (nkh * nkw * p.C) >> 6 : Ktot >> 6;
-  const uint16_t* wrow[GB];
+  int wrow[GB];          // element offset of this lane's chunk in filter row n
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     int rb = (wid * GB + i) * RPI + lrow;
     int n = n0 + rb;
     n = n < p.Ncols ? n : p.Ncols - 1;   // rows past Ncols read a valid row; their columns are never stored
-    wrow[i] = p.w + (size_t)n * Ktot + ((lslot ^ ((rb >> 1) & SWZ)) << 3);
+    wrow[i] = n * Ktot + ((lslot ^ ((rb >> 1) & SWZ)) << 3);
   }
 
   // running (channel-slice, tap) position of the NEXT stage to load: uniform scalars, no divisions
@@ -212,26 +213,26 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     }
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      const unsigned short* src = ((a_mask[i] >> tap) & 1u) ? p.x + (a_off[i] + delta) : zero;
+      unsigned vo = ((a_mask[i] >> tap) & 1u) ? 2u * (unsigned)(a_off[i] + delta) : kDmaOob;
 #ifdef MXDET_ABL_ZEROSRC
-      src = zero;
+      vo = kDmaOob;
 #endif
 #ifndef MXDET_ABL_NOLOAD
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, 0, 0, 0);
 #else
-      asm volatile("" ::"v"(src));
+      asm volatile("" ::"v"(vo));
 #endif
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const unsigned short* wsrc = wrow[i] + koff;
+      unsigned wo = 2u * (unsigned)(wrow[i] + koff);
 #ifdef MXDET_ABL_ZEROSRC
-      wsrc = zero;
+      wo = kDmaOob;
 #endif
 #ifndef MXDET_ABL_NOLOAD
-      __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16, (int)wo, 0, 0, 0);
 #else
-      asm volatile("" ::"v"(wsrc));
+      asm volatile("" ::"v"(wo));
 #endif
     }
     // K order = (channel slice, kh, kw) with the TAP fastest: the KH*KW shifted re-reads of one 128-B
@@ -280,13 +281,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       koff += live ? h * 32 : 0;
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
-        const unsigned short* src = ((a_mask[i] >> tap) & 1u) ? p.x + (a_off[i] + delta) : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, 0, 0);
+        const unsigned vo = ((a_mask[i] >> tap) & 1u) ? 2u * (unsigned)(a_off[i] + delta) : kDmaOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < GB; ++i) {
-        const unsigned short* wsrc = wrow[i] + koff;
-        __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(sbase + BM * 64 + (wid * GB + i) * 1024), 16, 0, 0);
+        const unsigned wo = 2u * (unsigned)(wrow[i] + koff);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 64 + (wid * GB + i) * 1024), 16, (int)wo, 0, 0, 0);
       }
       if (h == 1) {
         ++ld_kt;

@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "wgrad_tile.h"
+#include "wgrad_big.h"
 
 namespace mxdet {
 
@@ -62,6 +63,23 @@ wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __r
     }
     __syncthreads();                                 // LDS ring is reused by the next tile
   }
+}
+
+// the 256 x 256 tiles of a group (wgrad_big.h): 512 threads, 128 KiB of LDS, one workgroup per CU
+__global__ void __launch_bounds__(512)
+wgrad_grouped_big_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kBigLds];
+  const int bid = (int)blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid].bblock0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int b = bid - table[lo].bblock0;
+  if (b >= table[lo].bnblocks) return;             // alignment padding between layers
+  WgradP p = table[lo].p;
+  p.slab = (float*)(workspace + (size_t)p.slab);
+  wgrad_big_tile(p, b, smem);
 }
 
 // dw[i] (+)= sum_ks slab[ks][i] in index order; the trailing workgroups fold the bias partials the same way.
@@ -277,6 +295,12 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
 
 using namespace mxdet;
 
+#ifdef MXDET_WGB_STAMP
+extern "C" int mxdet_debug_read_wgb_stamps(unsigned long long* out /* host, 48 */) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgb_stamp), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -4;
+}
+#endif
+
 extern "C" int mxdet_debug_wgrad_group_persist(int32_t workgroups) {
   g_group_persist = workgroups;
   return MXDET_OK;
@@ -370,9 +394,9 @@ extern "C" size_t mxdet_conv2d_wgrad_grouped_table_bytes(int32_t n) {
 
 extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, void* table_host,
                                                size_t table_bytes, size_t* workspace_bytes, int32_t* grid_wgrad,
-                                               int32_t* grid_reduce) {
+                                               int32_t* grid_big, int32_t* grid_reduce) {
   clear_error();
-  MXDET_REQUIRE(items && n > 0 && table_host && workspace_bytes && grid_wgrad && grid_reduce, MXDET_EINVAL,
+  MXDET_REQUIRE(items && n > 0 && table_host && workspace_bytes && grid_wgrad && grid_big && grid_reduce, MXDET_EINVAL,
                 "wgrad_grouped_plan: null pointer or empty group");
   MXDET_REQUIRE(table_bytes >= (size_t)n * sizeof(WgradG), MXDET_EWORKSPACE, "wgrad_grouped_plan: table too small");
   WgradG* t = (WgradG*)table_host;
@@ -381,9 +405,45 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
   // pixels per workgroup: long enough K loops to amortise the 64-KiB slab a workgroup writes, short enough that the
   // group has a few thousand workgroups; never below 16 steps
   long long tiles_total = 0;
+  // Items wide enough for the 256 x 256 tile go to the 512-thread kernel. All of them get the same step count S per
+  // workgroup (64-pixel steps), the smallest S >= the minimum for which the group has at most the target number of
+  // workgroups: equal-length workgroups pack the rounds of 256 CUs evenly, whatever the map size of their layer.
+  const bool use_big = tuning(MXDET_TUNE_WGB_ENABLE) != 0;
+  // ... and long enough: a 256 x 256 workgroup costs ~13 us before and after its K loop (table lookup, first loads,
+  // 256 KiB of fp32 partial sums), which only the P2 / P3-sized maps amortise (tools/bench_wgrad.py)
+  const long long big_minpx = tuning(MXDET_TUNE_WGB_MINPX);
+  auto is_big = [&](const mxdet_conv_desc_t& d) {
+    return use_big && d.Cout >= 256 && d.Cin >= 256 && (long long)d.N * d.Ho * d.Wo >= big_minpx;
+  };
+  int big_S = 0;
+  {
+    const long long target = tuning(MXDET_TUNE_WGB_TARGET);
+    const int smin = (int)tuning(MXDET_TUNE_WGB_MINSTEPS);
+    auto count = [&](int S) {
+      long long c = 0;
+      for (int i = 0; i < n; ++i) {
+        const mxdet_conv_desc_t& d = items[i].desc;
+        if (!is_big(d)) continue;
+        const long long steps = ceil_div<long long>((long long)d.N * d.Ho * d.Wo, kBigPx);
+        long long ks = ceil_div<long long>(steps, S);
+        ks = ks > 64 ? 64 : ks;
+        c += (long long)ceil_div(d.Cout, 256) * ceil_div(d.Cin, 256) * d.KH * d.KW * ks;
+      }
+      return c;
+    };
+    int lo = smin < 1 ? 1 : smin, hi = 1 << 16;
+    if (count(lo) <= target) hi = lo;
+    while (lo < hi) {                         // count() is non-increasing in S
+      const int mid = (lo + hi) >> 1;
+      if (count(mid) <= target) hi = mid; else lo = mid + 1;
+    }
+    big_S = lo;
+  }
+  long long bblocks_total = 0;
   for (int i = 0; i < n; ++i)
-    tiles_total += (long long)ceil_div(items[i].desc.Cout, 128) * ceil_div(items[i].desc.Cin, 128) *
-                   items[i].desc.KH * items[i].desc.KW;
+    if (!is_big(items[i].desc))
+      tiles_total += (long long)ceil_div(items[i].desc.Cout, 128) * ceil_div(items[i].desc.Cin, 128) *
+                     items[i].desc.KH * items[i].desc.KW;
   for (int i = 0; i < n; ++i) {
     const mxdet_conv_desc_t* d = &items[i].desc;
     int rc = validate_wgrad_desc(d, "wgrad_grouped_plan");
@@ -399,6 +459,30 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
     p.M = d->N * d->Ho * d->Wo;
     p.co_tiles = ceil_div(d->Cout, 128); p.ci_tiles = ceil_div(d->Cin, 128);
     const int taps = d->KH * d->KW;
+    if (is_big(*d)) {
+      const int bsteps = ceil_div(p.M, kBigPx);
+      int ks = ceil_div(bsteps, big_S);
+      ks = ks > 64 ? 64 : ks;
+      p.big_steps_per_split = ceil_div(bsteps, ks);
+      p.big_ksplit = ceil_div(bsteps, p.big_steps_per_split);
+      p.big_co_tiles = ceil_div(d->Cout, 256); p.big_ci_tiles = ceil_div(d->Cin, 256);
+      p.big_nwg = p.big_co_tiles * p.big_ci_tiles * taps * p.big_ksplit;
+      // the bias partial sums stay with the 256-thread kernel, over the same pixel ranges
+      p.ksplit = p.big_ksplit;
+      p.steps_per_split = p.big_steps_per_split * (kBigPx / kWgradBKP);
+      p.nwg_main = 0;
+      g.nparams = (long long)d->Cout * taps * d->Cin;
+      g.nblocks = p.db ? p.co_tiles * p.ksplit : 0;
+      g.block0 = (int)blocks;
+      blocks += align_up((size_t)g.nblocks, 8);
+      g.bnblocks = p.big_nwg;
+      g.bblock0 = (int)bblocks_total;
+      bblocks_total += align_up((size_t)g.bnblocks, 8);
+      MXDET_REQUIRE(blocks < (1ll << 30) && bblocks_total < (1ll << 30), MXDET_ESHAPE, "wgrad_grouped_plan: group too large");
+      continue;
+    }
+    g.bblock0 = (int)bblocks_total;      // no 256 x 256 tiles: an empty range keeps the table sorted for the search
+    g.bnblocks = 0;
     const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
     const int steps = ceil_div(p.M, kWgradBKP);
     // aim for ~3000 workgroups over the group (3 rounds of the 1024 resident ones)
@@ -463,22 +547,27 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
   }
   *workspace_bytes = off;
   *grid_wgrad = (int32_t)blocks;
+  *grid_big = (int32_t)bblocks_total;
   *grid_reduce = (int32_t)rblocks;
   return MXDET_OK;
 }
 
-extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_reduce,
-                                          void* workspace, size_t workspace_bytes, size_t workspace_needed,
-                                          mxdet_stream_t stream) {
+extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
+                                          int32_t grid_reduce, void* workspace, size_t workspace_bytes,
+                                          size_t workspace_needed, mxdet_stream_t stream) {
   clear_error();
-  MXDET_REQUIRE(table_dev && n > 0 && grid_wgrad > 0, MXDET_EINVAL, "wgrad_grouped: empty group");
+  MXDET_REQUIRE(table_dev && n > 0 && grid_wgrad >= 0 && grid_big >= 0 && grid_wgrad + grid_big > 0, MXDET_EINVAL,
+                "wgrad_grouped: empty group");
   MXDET_REQUIRE(workspace_needed == 0 || (workspace && workspace_bytes >= workspace_needed), MXDET_EWORKSPACE,
                 "wgrad_grouped: workspace %zu < %zu", workspace_bytes, workspace_needed);
   hipStream_t s = as_stream(stream);
   // Optional chunking (tuning hook): a grid far larger than one resident round keeps the dispatcher on this queue until
   // it has placed every workgroup, which starves the short dgrad kernels of the main stream; chunks of about one
   // resident round let the two queues alternate at launch granularity.
-  const int chunk = g_group_chunk > 0 ? g_group_chunk : grid_wgrad;
+  if (grid_big > 0)
+    hipLaunchKernelGGL(wgrad_grouped_big_kernel, dim3((unsigned)grid_big), dim3(512), 0, s, (const WgradG*)table_dev, n,
+                       (unsigned char*)workspace);
+  const int chunk = g_group_chunk > 0 ? g_group_chunk : (grid_wgrad > 0 ? grid_wgrad : 1);
   const int persist = g_group_persist > 0 ? (g_group_persist + 7) & ~7 : 0;
   for (int off = 0; off < grid_wgrad; off += chunk) {
     const int cnt = grid_wgrad - off < chunk ? grid_wgrad - off : chunk;

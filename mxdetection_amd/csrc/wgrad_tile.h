@@ -25,11 +25,11 @@ struct WgradP {
   int M;               // N*Ho*Wo
   int co_tiles, ci_tiles, ksplit, steps_per_split;
   int nwg_main;        // MFMA workgroups; the grid continues with co_tiles*ksplit bias workgroups when db != null
+  // 256 x 256 tiles of the 512-thread kernel (wgrad_big.h; grouped launches only). An item is tiled by ONE of the two
+  // kernels: big_nwg > 0 means nwg_main == 0 and only the bias workgroups (if any) stay with the 256-thread kernel,
+  // with ksplit / steps_per_split describing the same pixel ranges as big_ksplit / big_steps_per_split.
+  int big_nwg, big_co_tiles, big_ci_tiles, big_ksplit, big_steps_per_split;
 };
-
-// 16 bytes of zeros read by out-of-range lanes, so that every global load is unconditional (a branch around a
-// load makes hipcc wait for each load separately: 8 serialized round trips per step)
-static __device__ __attribute__((aligned(256))) unsigned int g_wgrad_zero[64];
 
 // byte offset inside a [64 px][256 B] image of 16-B chunk c16 of pixel row `row`
 __device__ __forceinline__ int wg_off(int row, int c16) {
@@ -118,7 +118,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
   // DMA geometry: wave w, instruction i (0..3) fills pixel rows 4*(4w+i) .. +3 of both images; lane l covers
   // row (l>>4), physical 16-B slot (l&15), i.e. logical chunk ((slot>>1) ^ f(row)) * 2 + (slot & 1)
   const int lrow = lane >> 4, lslot = lane & 15;
-  const uint16_t* zero = (const uint16_t*)g_wgrad_zero;
+  // LDS-DMA in the buffer form: descriptor in SGPRs + 32-bit byte offset per lane (a fifth of the issue cost of 64-bit
+  // per-lane addresses, tools/micro/dma_rate.hip); out-of-range lanes write zeros by themselves
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(p.dy, 2u * (unsigned)p.M * (unsigned)p.Cout);
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(p.x, 2u * (unsigned)(p.N * p.H * p.W) * (unsigned)p.Cin);
   // Each lane walks its GI pixel rows BKP pixels per step with an exact carry chain (BKP = d_img*HW + d_ho*Wo + d_wo,
   // every component below its modulus), keeps 32-bit element offsets, and selects the zero page without branches.
   const int HW = p.Ho * p.Wo;
@@ -151,15 +154,13 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
       const bool yok = mok && c_yok[i];
       const bool xok = mok && c_xok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
       const int offx = ((c_img[i] * p.H + hi) * p.W + wi) * p.Cin + c_chx[i];
-      const uint16_t* ay = p.dy + (unsigned)c_offy[i];
-      const uint16_t* ax = p.x + (unsigned)offx;
-      const uint16_t* py = yok ? ay : zero;
-      const uint16_t* px = xok ? ax : zero;
+      const unsigned vy = yok ? 2u * (unsigned)c_offy[i] : kDmaOob;
+      const unsigned vx = xok ? 2u * (unsigned)offx : kDmaOob;
 #ifndef MXDET_ABL_NOLOAD
-      __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(smem[buf][0] + (wid * GI + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(smem[buf][1] + (wid * GI + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lptr_t)(smem[buf][0] + (wid * GI + i) * 1024), 16, (int)vy, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(smem[buf][1] + (wid * GI + i) * 1024), 16, (int)vx, 0, 0, 0);
 #else
-      asm volatile("" ::"v"(py), "v"(px));
+      asm volatile("" ::"v"(vy), "v"(vx));
 #endif
       // advance this row by BKP pixels
       c_m[i] += BKP;
@@ -290,6 +291,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
 struct WgradG {
   WgradP p;                 // slab / bslab hold byte offsets into the workspace
   int block0, nblocks;      // this layer's workgroups: [block0, block0 + nblocks), block0 a multiple of 8
+  int bblock0, bnblocks;    // the same in the 512-thread kernel's numbering (256 x 256 tiles)
   int rblock0, wblocks, bblocks;   // fold kernel: first workgroup, workgroups over dw, workgroups over db
   int fold_ksplit;                 // slabs the fold adds up (all items that share this item's dw write into one run)
   long long nparams;

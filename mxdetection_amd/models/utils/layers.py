@@ -106,7 +106,7 @@ class Workspace:
         if plan is None and not capturing:
             calls = [(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
                       l.arena.view(l.bi, "g") if l.train_bias else None, False) for l, x, dy in items]
-            plan = dense.GroupedWgrad(calls, self.device)
+            plan = dense.GroupedWgrad(calls, self.device, fused=self.fusing)
             self.plans[key] = plan
             if self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
                 self._retired.append(self.gbuf)

@@ -159,7 +159,7 @@ class GroupedWgrad:
     (x, dy, KH, KW, stride, pad, dw, db, accumulate); the plan (device table, grids, workspace size) is built once, in
     eager mode, and stays valid while the tensors keep their addresses (e.g. under hipGraph replay)."""
 
-    def __init__(self, calls, device):
+    def __init__(self, calls, device, fused=False):
         lib = _lib.load()
         n = len(calls)
         items = (_lib.WgradItemT * n)()
@@ -176,9 +176,16 @@ class GroupedWgrad:
                 self.heaviest = (fl, "N=%d %dx%d %d->%d %dx%d" % (N, H, W, Cin, dy.shape[3], KH, KW))
         nbytes = lib.mxdet_conv2d_wgrad_grouped_table_bytes(n)
         host = (C.c_ubyte * nbytes)()
-        ws, gw, gr = C.c_size_t(0), C.c_int32(0), C.c_int32(0)
-        check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gr)),
-              "conv2d_wgrad_grouped_plan")
+        ws, gw, gb, gr = C.c_size_t(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if fused:        # the fused backward launch slices the 256-thread kernel's tiles: no 256x256-tile items
+            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], 0)
+        try:
+            check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gb),
+                                                      C.byref(gr)), "conv2d_wgrad_grouped_plan")
+        finally:
+            if fused:
+                lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], -1)
+        self.grid_big = gb.value
         self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
         self.n, self.grid_wgrad, self.grid_reduce, self.workspace_bytes = n, gw.value, gr.value, ws.value
         b0 = (C.c_int32 * (n + 1))()
@@ -192,7 +199,7 @@ class GroupedWgrad:
                                                           self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped_from")
 
     def launch(self, workspace):
-        check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_reduce,
+        check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce,
                                                      ptr(workspace), workspace.numel() if workspace is not None else 0,
                                                      self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
 

@@ -320,3 +320,83 @@ def test_filter_transpose_batched_matches_permute(hip):
     torch.cuda.synchronize()
     for w, wt in pairs:
         assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
+
+
+def test_grouped_wgrad_big_tiles(hip, oracle):
+    """The 256x256-tile weight-gradient kernel (items with Cout, Cin >= 256 of a grouped launch) against torch-CPU fp32
+    on the same bf16 operands: partial tiles (448 output channels), stride 2, fully connected (1x1 maps), a filter shared
+    by two levels, bias gradients, kAddTo -- mixed in one group with an item of the 128x128-tile kernel. fp32
+    accumulation in a fixed order: rms-relative 1e-3."""
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(33)
+    torch.set_num_threads(8)
+    # (N, H, W, Cin, Cout, K, stride, pad, bias)
+    cases = [(2, 25, 42, 256, 256, 3, 1, 1, True),      # C4 conv2 shape, 2100 pixels
+             (2, 13, 21, 512, 448, 1, 1, 0, True),      # partial co tile (448 = 256 + 192)
+             (1, 26, 44, 256, 512, 3, 2, 1, False),     # stride 2
+             (300, 1, 1, 1024, 256, 1, 1, 0, True),     # fully connected: 300 rois, fewer than 5 steps
+             (2, 25, 42, 64, 128, 3, 1, 1, True)]       # narrow: stays with the 128x128-tile kernel
+    calls, refs = [], []
+    for N, H, W, Cin, Cout, K, s, pd, bias in cases:
+        Ho, Wo = (H + 2 * pd - K) // s + 1, (W + 2 * pd - K) // s + 1
+        x = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+        dy = _bf(rng, (N, Ho, Wo, Cout), 1.0, oracle)
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+        dyt = torch.from_numpy(dy).permute(0, 3, 1, 2)
+        gw = torch.nn.grad.conv2d_weight(xt, (Cout, Cin, K, K), dyt, stride=s, padding=pd).permute(0, 2, 3, 1).numpy()
+        gb = dy.reshape(-1, Cout).astype(np.float64).sum(0)
+        dw = torch.zeros((Cout, K, K, Cin), device="cuda")
+        db = torch.zeros((Cout,), device="cuda") if bias else None
+        calls.append((_t(x, torch.bfloat16), _t(dy, torch.bfloat16), K, K, s, pd, dw, db, False))
+        refs.append((gw, gb))
+    # one filter applied at two pyramid levels (RPN-style): the group sums the levels
+    Cs = 256
+    xs = [_bf(rng, (2, h, w, Cs), 1.0, oracle) for h, w in ((13, 21), (7, 11))]
+    dys = [_bf(rng, (2, h, w, Cs), 1.0, oracle) for h, w in ((13, 21), (7, 11))]
+    dw_s, db_s = torch.zeros((Cs, 3, 3, Cs), device="cuda"), torch.zeros((Cs,), device="cuda")
+    gw_s = sum(torch.nn.grad.conv2d_weight(torch.from_numpy(x).permute(0, 3, 1, 2), (Cs, Cs, 3, 3),
+                                           torch.from_numpy(d).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).numpy()
+               for x, d in zip(xs, dys))
+    gb_s = sum(d.reshape(-1, Cs).astype(np.float64).sum(0) for d in dys)
+    for x, d in zip(xs, dys):
+        calls.append((_t(x, torch.bfloat16), _t(d, torch.bfloat16), 3, 3, 1, 1, dw_s, db_s, False))
+    tune = hip.load().mxdet_debug_set_tuning
+    tune(hip.TUNING_KEYS["WGB_ENABLE"], 1)       # the kernel is off by default (DESIGN.md section 9, r02)
+    tune(hip.TUNING_KEYS["WGB_MINPX"], 0)        # small maps too
+    try:
+        plan = dense.GroupedWgrad(calls, "cuda")
+    finally:
+        tune(hip.TUNING_KEYS["WGB_MINPX"], -1)
+        tune(hip.TUNING_KEYS["WGB_ENABLE"], -1)
+    assert plan.grid_big > 0 and plan.grid_wgrad > 0          # both kernels take part
+    ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
+    plan.launch(ws)
+    torch.cuda.synchronize()
+
+    def rel(got, ref):
+        ref = np.asarray(ref, np.float64)
+        return float(np.sqrt(np.mean((np.asarray(got, np.float64) - ref) ** 2)) / (np.sqrt(np.mean(ref ** 2)) + 1e-30))
+    for (N, H, W, Cin, Cout, K, s, pd, bias), c, (gw, gb) in zip(cases, calls, refs):
+        assert rel(c[6].cpu().numpy(), gw) < 1e-3, (Cin, Cout, K, s, rel(c[6].cpu().numpy(), gw))
+        if bias:
+            assert rel(c[7].cpu().numpy(), gb) < 1e-3
+    assert rel(dw_s.cpu().numpy(), gw_s) < 1e-3 and rel(db_s.cpu().numpy(), gb_s) < 1e-3
+    # bit-reproducible (fixed split and fold order), and kAddTo through the fold
+    first = [c[6].clone() for c in calls]
+    plan.launch(ws)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, c[6]) for a, c in zip(first, calls))
+    acc_calls = [c[:8] + (True,) for c in calls[:2]]
+    base = [c[6].clone() for c in acc_calls]
+    tune(hip.TUNING_KEYS["WGB_ENABLE"], 1)
+    tune(hip.TUNING_KEYS["WGB_MINPX"], 0)
+    plan2 = dense.GroupedWgrad(acc_calls, "cuda")
+    tune(hip.TUNING_KEYS["WGB_MINPX"], -1)
+    tune(hip.TUNING_KEYS["WGB_ENABLE"], -1)
+    assert plan2.grid_big > 0
+    ws2 = torch.empty((max(plan2.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
+    plan2.launch(ws2)
+    torch.cuda.synchronize()
+    for b, c in zip(base, acc_calls):
+        assert rel(c[6].cpu().numpy(), 2.0 * b.cpu().numpy()) < 1e-6
