@@ -395,6 +395,11 @@ int mxdet_filter_transpose_batched(const void* descs_dev, int32_t ndesc, int32_t
  * (coalesced plane reads), + bias + ReLU, writing bf16 [N,Ho,Wo,64]; w bf16 [64,7,7,3]. */
 int mxdet_stem_conv7x7(const void* image, int32_t dtype, int32_t N, int32_t H, int32_t W,
                        const uint16_t* w, const float* bias, uint16_t* y, mxdet_stream_t stream);
+/* the same followed by the 3x3 stride-2 pad-1 max pooling, in one pass (the stem map is never written): y bf16
+ * [N,Hp,Wp,64] with Ho = (H-1)/2+1, Hp = (Ho-1)/2+1 (same for W); bits equal to maxpool3x3s2(stem_conv7x7) up to the
+ * order of the fp32 accumulation inside the convolution */
+int mxdet_stem_conv7x7_pool(const void* image, int32_t dtype, int32_t N, int32_t H, int32_t W,
+                            const uint16_t* w, const float* bias, uint16_t* y, mxdet_stream_t stream);
 /* 3x3 stride-2 pad-1 max pooling, bf16 channels-last */
 int mxdet_maxpool3x3s2(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y,
                        mxdet_stream_t stream);

@@ -138,6 +138,7 @@ SIGNATURES = {
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_filter_transpose_batched": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "mxdet_stem_conv7x7": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mxdet_stem_conv7x7_pool": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_maxpool3x3s2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_subsample2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_subsample2_bwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -163,7 +164,7 @@ SIGNATURES = {
 DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
                  "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
 TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "WGB_ENABLE": 6,
-               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9}
+               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9, "TAIL": 10}
 
 _lib = None
 

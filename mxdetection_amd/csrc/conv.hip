@@ -702,7 +702,13 @@ static int launch(ConvP& p, hipStream_t s) {
       p.m_begin = big.tiles_m * 256;
       if (p.m_begin >= p.M) return rc;
     }
-    return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+    // the remaining rows (a partial round of 256x256 tiles would idle most CUs for a whole tile time): small tiles,
+    // so that every CU gets a share of the tail (measured: 64x64 tiles 208 workgroups, vs 128x128 tiles 52 workgroups)
+    switch ((int)tuning(MXDET_TUNE_TAIL)) {
+      case 1: return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
+      case 2: return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
+      default: return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+    }
   }
   if (t64 >= thr_t64()) return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
   return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);

@@ -136,6 +136,212 @@ stem_conv_kernel(const void* __restrict__ img, int dtype, int N, int H, int W, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stem + max-pool fused: image [N,3,H,W] -> relu(conv7x7/2 + bias) -> maxpool 3x3/2 pad 1 -> bf16 [N,Hp,Wp,64], one pass.
+// The unfused pair writes the 68.8 MB stem map and reads it back to produce a quarter of it; here a workgroup owns
+// 2 pooled rows x 63 pooled columns: the 5 x 128 stem outputs underneath are computed row by row on the matrix pipes,
+// rounded to bf16 exactly where the unfused kernel rounds (max is monotonic: the pooled bits are those of
+// maxpool(stem) on the same accumulators), maxed vertically in registers and horizontally through LDS.
+//   LDS patch [15 rows][296 cols][4 ch] bf16 (channel 3 = 0): a k-run of 8 = 2 columns x 4 channels is 16 contiguous
+//   bytes, so an A fragment (16 stem outputs x 32 k) of filter row kh is ONE ds_read_b128 per lane at
+//   ((2r + kh) * 296 + 2 * col + 2 * fq) * 8 -- always 16-B aligned (the column stride of the conv is 2), consecutive
+//   chunks across lanes (conflict-free). K = 7 filter rows x (8 columns x 4 channels, column 7 and channel 3 zero).
+//   Waves are 2 x 2: wave (wm, wn) owns stem columns 64wm .. 64wm+63 (4 m-tiles) x output channels 32wn .. 32wn+31
+//   (2 n-tiles); its filters (2 n-tiles x 7 k-steps, 56 registers) stay in registers for the whole workgroup
+//   (all 64 channels per wave took 256+ registers: one workgroup per CU).
+constexpr int SP_PC = 63;                       // pooled columns per workgroup (stem columns 0..127 of the tile)
+constexpr int SP_PW = 296;                      // patch columns (2*127 + 7 + padding of the last fragment)
+constexpr int SP_ROWS = 15;                     // input rows under 5 stem rows
+constexpr int SP_PATCH_BYTES = SP_ROWS * SP_PW * 8;
+constexpr int SP_HB_BYTES = 2 * 128 * 64 * 2;   // two vertically pooled stem rows [128 cols][64 ch] bf16
+constexpr int SP_LDS = SP_PATCH_BYTES > SP_HB_BYTES ? SP_PATCH_BYTES : SP_HB_BYTES;
+
+template <typename T>
+__device__ __forceinline__ float stem_px(const T* p);
+template <>
+__device__ __forceinline__ float stem_px<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float stem_px<uint16_t>(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2)      // two waves per SIMD: at most 256 registers (the need is ~180)
+stem_pool_kernel(const T* __restrict__ img, int N, int H, int W, int Ho, int Wo, int Hp, int Wp,
+                 const uint16_t* __restrict__ w, const float* __restrict__ bias, uint16_t* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SP_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int wtiles = ceil_div(Wp, SP_PC), htiles = ceil_div(Hp, 2);
+  int b = blockIdx.x;
+  const int wt = b % wtiles; b /= wtiles;
+  const int ht = b % htiles;
+  const int n = b / htiles;
+  const int ph0 = 2 * ht, pw0 = wt * SP_PC;
+  const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;        // first stem row / column of the tile
+  const int ir0 = 2 * cr0 - 3, ic0 = 2 * cc0 - 3;        // first input row / column of the patch
+
+  // ---- filters -> registers: lane (frow = co within the n-tile, fq) holds k = 8fq..8fq+7 of filter row kh,
+  // i.e. columns 2fq, 2fq+1 x channels 0..3 (column 7 / channel 3 are zero padding)
+  // (the raw [64][147] filter goes through LDS first: 112 two-byte gathers per lane straight from global memory
+  // kept the address unit busy for ~14 us per workgroup)
+  {
+    const uint4* w4 = (const uint4*)w;                    // 64*147*2 B = 18816 B = 1176 x 16 B
+    for (int i = tid; i < 1176; i += 256) ((uint4*)smem)[i] = w4[i];
+  }
+  __syncthreads();
+  bf16x8_t bw[2][7];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint16_t* wr = (const uint16_t*)smem + (wn * 32 + j * 16 + frow) * 147;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+      s16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kw = 2 * fq + (e >> 2), c = e & 3;
+        v[e] = (kw < 7 && c < 3) ? (short)wr[(kh * 7 + kw) * 3 + c] : (short)0;
+      }
+      bw[j][kh] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  float bz[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bz[j] = bias ? bias[wn * 32 + j * 16 + frow] : 0.0f;
+  __syncthreads();                                        // the filter image is consumed: the patch may overwrite it
+
+  // ---- input patch -> LDS, 4 bf16 per (row, col): plane rows are contiguous, so loads coalesce along the column.
+  // Every load is unconditional (clamped coordinates, zero selected afterwards) and a whole pass of 15 rows x 3 planes
+  // is issued before the first value is used: inside `if (in range)` hipcc waits for each load separately, 30 dependent
+  // round trips per thread.
+  {
+    const size_t plane = (size_t)H * W;
+    const T* base = img + (size_t)(n * 3) * plane;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int col = tid + pass * 256;
+      if (pass == 1 && col >= SP_PW) break;
+      const int wi = ic0 + col;
+      const bool cok = wi >= 0 && wi < W;
+      const int wic = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+      float v[SP_ROWS][3];
+#pragma unroll
+      for (int r = 0; r < SP_ROWS; ++r) {
+        const int hi = ir0 + r;
+        const int hic = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+        const T* p0 = base + (size_t)hic * W + wic;
+        v[r][0] = stem_px<T>(p0);
+        v[r][1] = stem_px<T>(p0 + plane);
+        v[r][2] = stem_px<T>(p0 + 2 * plane);
+      }
+#pragma unroll
+      for (int r = 0; r < SP_ROWS; ++r) {
+        const int hi = ir0 + r;
+        const bool ok = cok && hi >= 0 && hi < H;
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16_bits(v[r][0]) | ((unsigned)f32_to_bf16_bits(v[r][1]) << 16);
+        o.y = (unsigned)f32_to_bf16_bits(v[r][2]);
+        if (!ok) o = make_uint2(0u, 0u);
+        *(uint2*)(smem + ((size_t)r * SP_PW + col) * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- five stem rows; vertical max of rows {0,1,2} and {2,3,4} in registers. Values are >= 0 after the ReLU, so (i) an
+  // out-of-range stem row / column contributes an exact 0, which never wins over the in-range pixel every window has,
+  // and (ii) bf16 bit patterns order like the values: the running maxima are kept as packed bf16 pairs and updated with
+  // packed 16-bit integer maxima (half the registers, a third of the instructions of the fp32 form).
+  typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  u16x2_t pmax[2][4][2][2];        // [pooled row][m-tile][n-tile][r pair]
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) pmax[q][i][j][r] = (u16x2_t){0, 0};
+  // tiles that touch no border of the stem map need no per-value validity select (wave-uniform test)
+  const bool interior = cr0 >= 0 && cr0 + 5 <= Ho && cc0 >= 0 && cc0 + 128 <= Wo;
+#pragma unroll
+  for (int cr = 0; cr < 5; ++cr) {
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+      bf16x8_t af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = wm * 64 + i * 16 + frow;                     // stem column inside the tile
+        af[i] = *(const bf16x8_t*)(smem + ((size_t)(2 * cr + kh) * SP_PW + 2 * col + 2 * fq) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bw[j][kh], acc[i][j], 0, 0, 0);
+    }
+    const bool rowok = (cr0 + cr) >= 0 && (cr0 + cr) < Ho;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // D layout: row = fq*4 + r -> stem column, col = frow -> channel
+      const int ccb = cc0 + wm * 64 + i * 16 + fq * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaxf(acc[i][j][r] + bz[j], 0.0f);
+          if (!interior) v[r] = (rowok && ccb + r >= 0 && ccb + r < Wo) ? v[r] : 0.0f;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // the stem map's own rounding (RNE, v_cvt_pk_bf16_f32), two values per register
+          const bf16x2_t pk = (bf16x2_t){(__bf16)v[2 * h], (__bf16)v[2 * h + 1]};
+          const u16x2_t u = __builtin_bit_cast(u16x2_t, pk);
+          if (cr <= 2) pmax[0][i][j][h] = __builtin_elementwise_max(pmax[0][i][j][h], u);
+          if (cr >= 2) pmax[1][i][j][h] = __builtin_elementwise_max(pmax[1][i][j][h], u);
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done with the patch: the LDS becomes hbuf
+  uint16_t* hb = (uint16_t*)smem;                    // [2][128 cols][64 ch]
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          hb[(q * 128 + wm * 64 + i * 16 + fq * 4 + r) * 64 + wn * 32 + j * 16 + frow] = pmax[q][i][j][r >> 1][r & 1];
+  __syncthreads();
+  // ---- horizontal max: pooled column pw <- stem columns 2pw, 2pw+1, 2pw+2 of the tile; 8 channels per lane
+  for (int it = tid; it < 2 * SP_PC * 8; it += 256) {
+    const int cg = it & 7, pw = (it >> 3) % SP_PC, q = (it >> 3) / SP_PC;
+    const int ph = ph0 + q, pwg = pw0 + pw;
+    if (ph >= Hp || pwg >= Wp) continue;
+    const uint4 a = *(const uint4*)(hb + (q * 128 + 2 * pw) * 64 + cg * 8);
+    const uint4 c = *(const uint4*)(hb + (q * 128 + 2 * pw + 1) * 64 + cg * 8);
+    const uint4 d = *(const uint4*)(hb + (q * 128 + 2 * pw + 2) * 64 + cg * 8);
+    // non-negative bf16 values order like their bit patterns: the max works on the packed halves directly
+    auto mx = [](unsigned x, unsigned y2) {
+      const unsigned lo = (x & 0xffffu) > (y2 & 0xffffu) ? (x & 0xffffu) : (y2 & 0xffffu);
+      const unsigned hi = (x >> 16) > (y2 >> 16) ? (x >> 16) : (y2 >> 16);
+      return lo | (hi << 16);
+    };
+    uint4 o;
+    o.x = mx(mx(a.x, c.x), d.x); o.y = mx(mx(a.y, c.y), d.y); o.z = mx(mx(a.z, c.z), d.z); o.w = mx(mx(a.w, c.w), d.w);
+    *(uint4*)(y + (((size_t)n * Hp + ph) * Wp + pwg) * 64 + cg * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void unpack8f(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -387,6 +593,25 @@ extern "C" int mxdet_stem_conv7x7(const void* image, int32_t dtype, int32_t N, i
   hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)nwg), dim3(256), 0, as_stream(stream), image, dtype,
                      N, H, W, Ho, Wo, w, bias, y);
   return check_launch("stem_conv7x7");
+}
+
+extern "C" int mxdet_stem_conv7x7_pool(const void* image, int32_t dtype, int32_t N, int32_t H, int32_t W,
+                                       const uint16_t* w, const float* bias, uint16_t* y, mxdet_stream_t stream) {
+  clear_error();
+  MXDET_REQUIRE(N > 0 && H > 0 && W > 0, MXDET_ESHAPE, "stem_conv7x7_pool: bad shape");
+  MXDET_REQUIRE(dtype == MXDET_DTYPE_F32 || dtype == MXDET_DTYPE_BF16, MXDET_EINVAL, "stem_conv7x7_pool: dtype");
+  MXDET_REQUIRE(image && w && y, MXDET_EINVAL, "stem_conv7x7_pool: null pointer");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  const long long nwg = (long long)N * ceil_div(Hp, 2) * ceil_div(Wp, SP_PC);
+  MXDET_REQUIRE(nwg < (1ll << 31), MXDET_ESHAPE, "stem_conv7x7_pool: image too large");
+  if (dtype == MXDET_DTYPE_F32)
+    hipLaunchKernelGGL(stem_pool_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, as_stream(stream), (const float*)image,
+                       N, H, W, Ho, Wo, Hp, Wp, w, bias, y);
+  else
+    hipLaunchKernelGGL(stem_pool_kernel<uint16_t>, dim3((unsigned)nwg), dim3(256), 0, as_stream(stream),
+                       (const uint16_t*)image, N, H, W, Ho, Wo, Hp, Wp, w, bias, y);
+  return check_launch("stem_conv7x7_pool");
 }
 
 extern "C" int mxdet_maxpool3x3s2(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -130,10 +130,10 @@ class ResNet:
         N, _, H, W = image.shape
         H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         dev = self.stem_w.device
-        x = dense.stem_conv7x7(image, self.stem_w, self.stem_b,
-                               cached_buf(self.bufs, "stem", (N, H1, W1, 64), torch.bfloat16, dev))
-        x = dense.maxpool3x3s2(x, cached_buf(self.bufs, "pool", (N, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1, 64),
-                                             torch.bfloat16, dev))
+        # stem + max-pool in one pass: the frozen front end never writes its 2x-resolution map
+        x = dense.stem_conv7x7_pool(image, self.stem_w, self.stem_b,
+                                    cached_buf(self.bufs, "pool", (N, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1, 64),
+                                               torch.bfloat16, dev))
         outs = []
         for st in self.stages:
             for b in st:

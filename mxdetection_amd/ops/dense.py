@@ -243,6 +243,19 @@ def stem_conv7x7(image, w, bias=None, out=None):
     return out
 
 
+def stem_conv7x7_pool(image, w, bias=None, out=None):
+    """Stem convolution + bias + ReLU + 3x3/2 max-pool in one pass: NCHW image -> bf16 [N,Hp,Wp,64]."""
+    lib = _lib.load()
+    N, _, H, W = image.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Hp, Wp, 64), dtype=torch.bfloat16, device=image.device)
+    check(lib.mxdet_stem_conv7x7_pool(ptr(image), _DT[image.dtype], N, H, W, ptr(w), ptr(bias), ptr(out), stream_ptr()),
+          "stem_conv7x7_pool")
+    return out
+
+
 def maxpool3x3s2(x, out=None):
     lib = _lib.load()
     N, H, W, Cc = x.shape

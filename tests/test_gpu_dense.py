@@ -208,6 +208,23 @@ def test_stem_and_maxpool(hip, oracle):
     pooled = dense.maxpool3x3s2(y)
     want = oracle.maxpool3x3s2(y.float().cpu().numpy())
     assert np.array_equal(pooled.float().cpu().numpy(), want)
+    # fused stem + max-pool (the path the backbone takes): same rounding points as the pair above, only the order of
+    # the fp32 accumulation inside the convolution differs -> within the stem tolerance of maxpool(reference stem), and
+    # bit-equal to maxpool of the unfused map wherever the two accumulations round to the same bf16 (almost everywhere)
+    for image in (_t(img), _t(img, torch.bfloat16)):
+        fused = dense.stem_conv7x7_pool(image, _t(w, torch.bfloat16), _t(bias))
+        assert tuple(fused.shape) == tuple(pooled.shape)
+        _close(fused.float().cpu().numpy(), oracle.maxpool3x3s2(oracle.round_bf16(ref)), "fused stem+pool")
+        assert float((fused != pooled).float().mean()) < 0.02
+    # odd sizes: partial tiles in both directions, a single pooled row, out-of-range stem rows / columns
+    for (h2, w2) in ((9, 131), (6, 510), (33, 64)):
+        im2 = rng.standard_normal((1, 3, h2, w2)).astype(np.float32)
+        y2 = dense.stem_conv7x7(_t(im2), _t(w, torch.bfloat16), _t(bias))
+        f2 = dense.stem_conv7x7_pool(_t(im2), _t(w, torch.bfloat16), _t(bias))
+        p2 = dense.maxpool3x3s2(y2)
+        assert tuple(f2.shape) == tuple(p2.shape)
+        ref2 = np.maximum(_torch_conv(oracle.round_bf16(im2).transpose(0, 2, 3, 1).copy(), w, 2, 3) + bias, 0)
+        _close(f2.float().cpu().numpy(), oracle.maxpool3x3s2(oracle.round_bf16(ref2)), "fused stem+pool %dx%d" % (h2, w2))
 
 
 def test_resampling_and_elementwise(hip, oracle):

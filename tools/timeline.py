@@ -9,7 +9,7 @@ with open(sys.argv[1]) as f:
                      r.get("Queue_Id", "0")))
 rows.sort()
 # a step starts with the stem kernel; take the window between the third- and second-last launches of it
-sgd = [i for i, r in enumerate(rows) if "stem_conv_kernel" in r[2]]
+sgd = [i for i, r in enumerate(rows) if "stem_conv_kernel" in r[2] or "stem_pool_kernel" in r[2]]
 if len(sgd) < 3:
     sys.exit("need >= 3 steps in the trace")
 lo, hi = sgd[-3], sgd[-2]
