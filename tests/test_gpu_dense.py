@@ -417,3 +417,50 @@ def test_grouped_wgrad_big_tiles(hip, oracle):
     torch.cuda.synchronize()
     for b, c in zip(base, acc_calls):
         assert rel(c[6].cpu().numpy(), 2.0 * b.cpu().numpy()) < 1e-6
+
+
+# every distinct (Cin, Cout, K, stride) of the trainable R50-FPN / heads, at a reduced map size
+LAYER_SHAPES = [
+    (512, 128, 1, 1), (128, 128, 3, 1), (128, 512, 1, 1), (256, 128, 1, 1), (128, 128, 3, 2), (256, 512, 1, 2),   # layer2
+    (1024, 256, 1, 1), (256, 256, 3, 1), (256, 1024, 1, 1), (512, 256, 1, 1), (256, 256, 3, 2), (512, 1024, 1, 2),  # layer3
+    (2048, 512, 1, 1), (512, 512, 3, 1), (512, 2048, 1, 1), (1024, 512, 1, 1), (512, 512, 3, 2), (1024, 2048, 1, 2),  # layer4
+    (256, 256, 1, 1), (2048, 256, 1, 1), (256, 64, 1, 1),                                                          # FPN laterals, RPN out
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride", LAYER_SHAPES)
+def test_layer_gradients_vs_torch_fp32(hip, oracle, Cin, Cout, K, stride):
+    """Layer-by-layer backward parity, so that the end-to-end 8 % bound (test_gpu_model_parity) is not the only backward
+    check: identical bf16 x, dy, w to the HIP dgrad / wgrad and to torch-CPU fp32 autograd. Weight gradients (fp32
+    accumulators, fp32 out): rms-relative error <= 1e-3 (measured ~1e-6). Data gradients are STORED in bf16: compared
+    with the fp32 result rounded to bf16, <= 1e-3 rms-relative (one-ulp flips where the two accumulation orders straddle
+    a rounding boundary) and bit-equal in > 98 % of the elements."""
+    import torch
+    from mxdetection_amd.ops import dense
+    rng = np.random.default_rng(100 + Cin + Cout + K + stride)
+    torch.set_num_threads(8)
+    N, H, W = 2, 14, 22
+    pad = K // 2
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    x = _bf(rng, (N, H, W, Cin), 1.0, oracle)
+    w = _bf(rng, (Cout, K, K, Cin), (2.0 / (K * K * Cin)) ** 0.5, oracle)
+    dy = _bf(rng, (N, Ho, Wo, Cout), 1.0, oracle)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wt_ = torch.from_numpy(w).permute(0, 3, 1, 2).requires_grad_(True)
+    yt = torch.nn.functional.conv2d(xt, wt_, stride=stride, padding=pad)
+    yt.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dx_ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    dw_ref = wt_.grad.permute(0, 2, 3, 1).numpy()
+    wdev = _t(w, torch.bfloat16)
+    dx = dense.conv2d_dgrad(_t(dy, torch.bfloat16), dense.filter_transpose(wdev), (N, H, W, Cin), K, K, stride, pad)
+    dw = dense.conv2d_wgrad(_t(x, torch.bfloat16), _t(dy, torch.bfloat16), K, K, stride, pad)
+    torch.cuda.synchronize()
+
+    def rel(got, ref):
+        ref = np.asarray(ref, np.float64)
+        return float(np.sqrt(np.mean((np.asarray(got, np.float64) - ref) ** 2)) / (np.sqrt(np.mean(ref ** 2)) + 1e-30))
+    assert rel(dw.cpu().numpy(), dw_ref) <= 1e-3, rel(dw.cpu().numpy(), dw_ref)
+    want = oracle.round_bf16(dx_ref.astype(np.float32))
+    got = dx.float().cpu().numpy()
+    assert rel(got, want) <= 1e-3, rel(got, want)
+    assert float((got != want).mean()) < 0.02

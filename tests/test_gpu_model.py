@@ -45,19 +45,60 @@ def test_train_step_runs_and_is_deterministic(hip):
     assert g0.abs().sum().item() > 0
 
 
-def test_loss_decreases_on_a_fixed_batch(hip):
+def test_detector_learns_a_fixed_batch(hip):
+    """The detector can fit something: 400 replayed steps on ONE fixed 2-image batch (three objects painted into noise)
+    drive the box-head classification loss below 0.2 and every RPN / box loss far below its start, and predict() then
+    returns exactly the ground truth: every GT box recovered at IoU >= 0.5 with its class, nothing else above score 0.3.
+    The net has no normalisation layers and is positively homogeneous, so the input scale (0.2) sets the logit scale of
+    the random-init heads (start: box-head CE = ln 81); lr 0.01 with a 50-step warm-up."""
     import torch
     from mxdetection_amd.models import FasterRCNN
     N, H, W = 2, 256, 320
-    image, gt, im_info = _inputs(N, H, W, seed=1)
-    m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
-    hist = []
-    for it in range(12):
-        rpn, rcnn = m.train_step(image, gt, im_info, step=0, image_offset=0, lr=0.001)
-        hist.append(float((rpn.sum() + rcnn.sum()).item()))
-    assert np.all(np.isfinite(hist)), hist
-    # SGD on a random-init net without BN is noisy step to step (the box-head CE spikes); the trend is what is checked
-    assert min(hist[-4:]) < 0.8 * hist[0], hist
+    image = torch.randn((N, 3, H, W), generator=torch.Generator().manual_seed(5)).cuda()
+    gt = -torch.ones((N, 8, 5))
+    gt[0, 0] = torch.tensor([30.0, 40.0, 150.0, 200.0, 3.0])
+    gt[0, 1] = torch.tensor([180.0, 60.0, 300.0, 180.0, 17.0])
+    gt[1, 0] = torch.tensor([60.0, 30.0, 260.0, 230.0, 40.0])
+    for n in range(N):
+        for k in range(8):
+            if gt[n, k, 4] > 0:
+                x1, y1, x2, y2, c = [int(v) for v in gt[n, k]]
+                image[n, :, y1:y2, x1:x2] += torch.tensor([1.5, -1.0, 0.5]).view(3, 1, 1).cuda() * (1 + 0.1 * c)
+    image *= 0.2
+    gt = gt.cuda()
+    info = torch.tensor([[H, W, 1.0]] * N).cuda()
+    m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=300, rois_per_image=128)
+    m.enable_wgrad_stream()
+    m.enable_branch_stream()
+    m.enable_grouped_wgrad()
+    lr = 0.01
+    m.capture(image, gt, info, lr=lr)
+    first = None
+    for it in range(400):
+        losses = m.replay(image, gt, info, it, lr=lr * min(1.0, (it + 1) / 50.0))
+        if it == 0:
+            torch.cuda.synchronize()
+            first = torch.cat(list(losses)).cpu().numpy().copy()
+    torch.cuda.synchronize()
+    last = torch.cat(list(losses)).cpu().numpy()
+    assert np.all(np.isfinite(last)), last
+    assert 3.5 < first[2] < 5.5, first                      # ~ln 81 at the start
+    assert last[2] < 0.2 and last[0] < 0.1 * first[0] and last[1] < 0.5 * first[1], (first, last)
+    dets, num = m.predict(image, info, score_thresh=0.3)
+    torch.cuda.synchronize()
+    d, nn, g = dets.cpu().numpy(), num.cpu().numpy(), gt.cpu().numpy()
+
+    def iou(a, b):
+        iw = min(a[2], b[2]) - max(a[0], b[0]) + 1
+        ih = min(a[3], b[3]) - max(a[1], b[1]) + 1
+        inter = max(iw, 0) * max(ih, 0)
+        return inter / ((a[2] - a[0] + 1) * (a[3] - a[1] + 1) + (b[2] - b[0] + 1) * (b[3] - b[1] + 1) - inter)
+    for n in range(N):
+        boxes = [b for b in g[n] if b[4] > 0]
+        assert int(nn[n]) == len(boxes), (n, nn[n], d[n, :int(nn[n])])
+        for b in boxes:
+            hits = [k for k in range(int(nn[n])) if int(d[n, k, 5]) == int(b[4]) and iou(d[n, k, :4], b[:4]) >= 0.5]
+            assert hits, (n, b, d[n, :int(nn[n])])
 
 
 def test_wgrad_side_stream_and_graph_replay_match_eager(hip):
