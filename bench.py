@@ -65,15 +65,24 @@ class ConvTimer:
         from mxdetection_amd.ops import dense
         timer = self
 
-        def wrap(name, family, flops_of):
+        def wrap(name, family, flops_of, shape_of):
             fn = getattr(dense, name)
             timer.orig[name] = fn
 
             def inner(*a, **kw):
                 if timer.logging:
-                    timer.log.append((family, flops_of(*a, **kw), fn, a, kw))
+                    timer.log.append((family, flops_of(*a, **kw), fn, a, kw, shape_of(*a, **kw)))
                 return fn(*a, **kw)
             setattr(dense, name, inner)
+
+        def s_fwd(x, w, *a, **kw):
+            return "N=%d %dx%d %d->%d %dx%d" % (x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], w.shape[1], w.shape[2])
+
+        def s_dgrad(dy, wt, x_shape, KH, KW, *a, **kw):
+            return "N=%d %dx%d %d->%d %dx%d" % (x_shape[0], x_shape[1], x_shape[2], x_shape[3], dy.shape[3], KH, KW)
+
+        def s_wgrad(x, dy, KH, KW, *a, **kw):
+            return "N=%d %dx%d %d->%d %dx%d" % (x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.shape[3], KH, KW)
 
         def f_fwd(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None):
             N, H, W, Cin = x.shape
@@ -89,16 +98,16 @@ class ConvTimer:
             N, Ho, Wo, Cout = dy.shape
             return 2.0 * N * Ho * Wo * Cout * KH * KW * x.shape[3]
 
-        wrap("conv2d_forward", "conv_igemm_fwd", f_fwd)
-        wrap("conv2d_dgrad", "conv_igemm_dgrad", f_dgrad)
-        wrap("conv2d_wgrad", "conv_wgrad", f_wgrad)
+        wrap("conv2d_forward", "conv_igemm_fwd", f_fwd, s_fwd)
+        wrap("conv2d_dgrad", "conv_igemm_dgrad", f_dgrad, s_dgrad)
+        wrap("conv2d_wgrad", "conv_wgrad", f_wgrad, s_wgrad)
         # grouped weight gradients (one launch pair per parameter bucket) are launches of the same family
         orig_launch = dense.GroupedWgrad.launch
         timer.orig["GroupedWgrad.launch"] = orig_launch
 
         def grouped_launch(plan, workspace):
             if timer.logging:
-                timer.log.append(("conv_wgrad", plan.flops, orig_launch, (plan, workspace), {}))
+                timer.log.append(("conv_wgrad", plan.flops, orig_launch, (plan, workspace), {}, "group of %d layers" % plan.n))
             return orig_launch(plan, workspace)
         dense.GroupedWgrad.launch = grouped_launch
         orig_glaunch = dense.GroupedConv.launch
@@ -107,7 +116,7 @@ class ConvTimer:
         def grouped_conv_launch(plan):
             if timer.logging:
                 timer.log.append(("conv_igemm_fwd" if plan.kind == 0 else "conv_igemm_dgrad", plan.flops, orig_glaunch,
-                                  (plan,), {}))
+                                  (plan,), {}, "group of %d layers" % plan.n))
             return orig_glaunch(plan)
         dense.GroupedConv.launch = grouped_conv_launch
 
@@ -132,7 +141,7 @@ class ConvTimer:
 
     def measure(self):
         fam = {}
-        for family, flops, fn, a, kw in self.log:
+        for family, flops, fn, a, kw, shape in self.log:
             t = self.time_launch(fn, a, kw, self.REPS)
             acc = fam.setdefault(family, [0.0, 0.0, 0])
             acc[0] += flops
@@ -140,7 +149,7 @@ class ConvTimer:
             acc[2] += 1
             grouped = fn in (self.orig.get("GroupedWgrad.launch"), self.orig.get("GroupedConv.launch"))   # "heaviest" = the largest SINGLE-layer launch
             if not grouped and (family not in self.heaviest or flops > self.heaviest[family][0]):
-                self.heaviest[family] = (flops, t)
+                self.heaviest[family] = (flops, t, shape)
         return fam
 
 
@@ -382,20 +391,25 @@ def main():
                         "unit": "TFLOP/s", "frac": round(fl / tt / MFMA_PEAK_BF16, 4), "traffic": None,
                         "launches_per_step": n, "avg_launch_ms": round(1e3 * tt / n, 4),
                         "method": "each conv launch of one step re-issued 8x inside a hipGraph replayed between HIP events"}
-        # heaviest single launch of the dominant family (the P2-level 3x3 layer), with the HBM traffic measured for
-        # exactly that launch in separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
-        if roofline is not None and timer.heaviest.get(roofline["kernel"]):
-            hfl, ht = timer.heaviest[roofline["kernel"]]
-            traffic = None
+        # `traffic` = HBM-side bytes (L2 misses) of the WHOLE dominant family in one step, from the tracked summary of
+        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over an eager step (tools/pmc_step.sh; FETCH_SIZE
+        # doubled for 16-B-per-lane reads as the microarch guide prescribes). It is measured evidence of this round's
+        # kernels, not of this very run: `traffic_source` names the file.
+        if roofline is not None and args.model == "faster_rcnn":
+            src = os.path.join("profiles", "r02_pmc_step.json")
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = json.load(f).get(roofline["kernel"], {}).get("hbm_bytes")
+                with open(os.path.join(ROOT, src)) as f:
+                    pm = json.load(f)
+                roofline["traffic"] = pm["families"][roofline["kernel"]]["hbm_bytes"]
+                roofline["traffic_source"] = src
+                roofline["traffic_scope"] = "all %d launches of the family in one step" % pm["families"][roofline["kernel"]]["launches_per_step"]
             except Exception:  # noqa: BLE001
-                traffic = None
-            roofline["heaviest_launch"] = {"shape": "N=2 200x336 256->256 3x3", "gflop": round(hfl / 1e9, 1),
+                roofline["traffic"] = None
+        if roofline is not None and timer.heaviest.get(roofline["kernel"]):
+            hfl, ht, hshape = timer.heaviest[roofline["kernel"]]
+            roofline["heaviest_launch"] = {"shape": hshape, "gflop": round(hfl / 1e9, 1),
                                            "ms": round(1e3 * ht, 4), "achieved": round(hfl / ht / 1e12, 1),
-                                           "frac": round(hfl / ht / MFMA_PEAK_BF16, 4), "traffic_bytes": traffic}
-            roofline["traffic"] = traffic
+                                           "frac": round(hfl / ht / MFMA_PEAK_BF16, 4)}
         out = {
             "metric": {"faster_rcnn": "images/sec (whole node) Faster R-CNN R50-FPN 3x800x1333",
                        "mask_rcnn": "images/sec (whole node) Mask R-CNN R50-FPN 3x800x1333",

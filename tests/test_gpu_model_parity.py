@@ -57,19 +57,22 @@ def test_step_matches_cpu_restatement(hip, oracle):
         rms = np.sqrt((r ** 2).mean())
         assert np.abs(g - r).max() <= 0.06 * rms + 0.03 * np.abs(r).max(), (l, np.abs(g - r).max(), rms)
         assert np.all(h[..., 5 * A:HEAD_CPAD] == 0)   # padding channels: zero filters, zero bias, zero gradient
-    # losses: within 2% (bf16 activations) of the fp32 CPU restatement
-    assert np.allclose(got_losses, out["losses"], rtol=2e-2, atol=2e-3), (got_losses, out["losses"])
+    # losses: within 0.5% (bf16 activations; measured 3e-4 .. 2e-3) of the fp32 CPU restatement
+    assert np.allclose(got_losses, out["losses"], rtol=5e-3, atol=1e-3), (got_losses, out["losses"])
     # gradients: relative L2 error per parameter tensor. Activations AND gradients are stored in bf16 (2^-9 relative
-    # rounding per tensor), so the error grows with depth: measured 0.3-3% for heads/FPN/C5 and ~5% at the far end of
-    # backward (layer2, ~45 bf16 tensors away from the loss). Bound: 8%.
+    # rounding per tensor), so the error grows with depth. Bounds = twice the values measured in round 2 (the kernels'
+    # own arithmetic is checked layer by layer at 1e-3 in tests/test_gpu_dense.py::test_layer_gradients_vs_torch_fp32;
+    # what accumulates here is the bf16 storage of ~50 tensors between the loss and layer2).
     grads = m.export_grads()
+    bounds = {"bbox.fc_out.weight": 3e-3, "bbox.fc1.weight": 2e-2, "rpn.out.weight": 5e-3, "rpn.conv.weight": 3.2e-2,
+              "fpn.out2.weight": 1.8e-2, "fpn.lat5.weight": 2e-2, "fpn.lat2.weight": 1.8e-2, "layer4.2.conv3.weight": 3.2e-2,
+              "layer4.0.down.weight": 4.5e-2, "layer3.0.conv2.weight": 6.6e-2, "layer2.0.conv1.weight": 8e-2,
+              "bbox.fc2.bias": 1.3e-2, "fpn.out3.bias": 1.2e-1, "rpn.conv.bias": 3.3e-2}
     worst = 0.0
-    for name in ["bbox.fc_out.weight", "bbox.fc1.weight", "rpn.out.weight", "rpn.conv.weight", "fpn.out2.weight",
-                 "fpn.lat5.weight", "fpn.lat2.weight", "layer4.2.conv3.weight", "layer4.0.down.weight",
-                 "layer3.0.conv2.weight", "layer2.0.conv1.weight", "bbox.fc2.bias", "fpn.out3.bias", "rpn.conv.bias"]:
+    for name, bound in bounds.items():
         g, r = grads[name].numpy().ravel(), out["grads"][name].numpy().ravel()
         rel = np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-30)
         worst = max(worst, rel)
         print("grad rel-L2", name, float(rel))
-        assert rel < 8e-2, (name, rel)
+        assert rel < bound, (name, rel, bound)
     print("losses hip", got_losses, "ref", out["losses"], "worst grad rel-L2", worst)
