@@ -76,6 +76,24 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return mxdet_f32_to_bf16(f); }
+// two floats -> packed bf16 pair by the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even: the same bits as
+// mxdet_f32_to_bf16 for every finite value; NaNs keep being NaNs). One instruction instead of ~12 integer ones: used
+// by the dense epilogues, whose results are tolerance-checked; the bit-exact detection ops keep the shared helper.
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t p = (bf16x2_t){(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, p);
+}
+// exact floor(n / d) and remainder for 0 <= n < 2^24 through one float multiply + a +-1 correction (an integer division
+// is ~40 instructions): the tile prologues do two per row
+__device__ __forceinline__ int fast_divmod(int n, int d, float rcp, int* rem) {
+  int q = (int)((float)n * rcp);
+  int r = n - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  *rem = r;
+  return q;
+}
 
 __device__ __forceinline__ float load_as_f32(const void* p, int64_t i, int dtype) {
   if (dtype == MXDET_DTYPE_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);

@@ -54,6 +54,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#ifdef MXDET_CONV_STAMP
+// diagnostic build (tools/build_conv_stamp.sh): cycle stamps of one workgroup's life, wave 0 of blocks 0 and 300:
+// [start, geometry done, first stage landed, K loop done, end]
+__device__ unsigned long long g_conv_stamp[2][8];
+#define MXDET_CS(k) do { if (cs_on) cs[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MXDET_CS(k) do { } while (0)
+#endif
+
 // Tile BM x BN x 64 per stage, WM x WN waves each owning a (BM/WM) x (BN/WN) accumulator tile.
 // Global -> LDS goes through an NS-deep ring filled by global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave
 // instruction = 8 tile rows): the loads of stage t+NS-1 are issued while stage t is being multiplied, so
@@ -93,6 +102,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
+#ifdef MXDET_CONV_STAMP
+  const bool cs_on = (blockIdx.x == 0 || blockIdx.x == 300) && wid == 0;
+  unsigned long long cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  MXDET_CS(0);
 
   // XCD-aware tile order: blocks that share an XCD (bid % 8) walk consecutive tiles, and consecutive
   // tiles share their A rows (n fastest), so the A tile is re-read from that XCD's L2.
@@ -134,6 +148,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(p.x, 2u * (unsigned)(p.N * p.Hs * p.Ws) * (unsigned)p.C);
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.w, 2u * (unsigned)p.Ncols * (unsigned)(p.KH * p.KW * p.C));
   const int ntaps = p.KH * p.KW;
+  const int hw_d = p.Hd * p.Wd;
+  const bool smallm = p.M < (1 << 24);
+  const float rcp_hw = 1.0f / (float)hw_d, rcp_w = 1.0f / (float)p.Wd;
   int a_off[GA];
   unsigned a_mask[GA];
 #pragma unroll
@@ -158,28 +175,48 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
             if (hs >= 0 && ws >= 0 && hs < p.Hs && ws < p.Ws) mask |= 1u << (a * nkw + b);
           }
       }
+    } else if (ntaps == 1 && p.stride == 1 && p.pad == 0) {
+      // 1x1 / stride 1 (half of the layers of a bottleneck stack, every FC): the source pixel IS the destination
+      // pixel -- no divisions, one tap (the general path below is ~40 instructions per division, six per row)
+      if (m < p.M) { off = m * p.C + coff; mask = 1u; }
     } else
     if (m < p.M) {
-      int img = m / (p.Hd * p.Wd);
-      int rem = m - img * (p.Hd * p.Wd);
-      int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+      int img, hd, wd, rem;
+      if (smallm) {       // M < 2^24: exact division by a float reciprocal (wave-uniform choice)
+        img = fast_divmod(m, hw_d, rcp_hw, &rem);
+        hd = fast_divmod(rem, p.Wd, rcp_w, &wd);
+      } else {
+        img = m / hw_d; rem = m - img * hw_d;
+        hd = rem / p.Wd; wd = rem - hd * p.Wd;
+      }
       int h0, w0;   // source position of tap (0,0)
-      if (DGRAD) { h0 = (hd + p.pad) / p.stride; w0 = (wd + p.pad) / p.stride; }
-      else { h0 = hd * p.stride - p.pad; w0 = wd * p.stride - p.pad; }
+      if (DGRAD) {
+        if (p.stride == 1) { h0 = hd + p.pad; w0 = wd + p.pad; }
+        else { h0 = (hd + p.pad) / p.stride; w0 = (wd + p.pad) / p.stride; }
+      } else { h0 = hd * p.stride - p.pad; w0 = wd * p.stride - p.pad; }
       off = ((img * p.Hs + h0) * p.Ws + w0) * p.C + coff;
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw) {
-          bool ok;
-          if (DGRAD) {
+      if (DGRAD && p.stride != 1) {
+        for (int kh = 0; kh < p.KH; ++kh)
+          for (int kw = 0; kw < p.KW; ++kw) {
             int th = hd + p.pad - kh, tw = wd + p.pad - kw;
             int hs = th / p.stride, ws = tw / p.stride;
-            ok = th >= 0 && tw >= 0 && th == hs * p.stride && tw == ws * p.stride && hs < p.Hs && ws < p.Ws;
-          } else {
-            int hs = h0 + kh, ws = w0 + kw;
-            ok = hs >= 0 && ws >= 0 && hs < p.Hs && ws < p.Ws;
+            bool ok = th >= 0 && tw >= 0 && th == hs * p.stride && tw == ws * p.stride && hs < p.Hs && ws < p.Ws;
+            if (ok) mask |= 1u << (kh * p.KW + kw);
           }
-          if (ok) mask |= 1u << (kh * p.KW + kw);
+      } else {
+        // a tap is inside the map iff its row and its column are: two small bit masks instead of KH*KW tests
+        unsigned rowm = 0, colm = 0;
+        for (int kh = 0; kh < p.KH; ++kh) {
+          const int hs = DGRAD ? h0 - kh : h0 + kh;
+          if (hs >= 0 && hs < p.Hs) rowm |= 1u << kh;
         }
+        for (int kw = 0; kw < p.KW; ++kw) {
+          const int ws = DGRAD ? w0 - kw : w0 + kw;
+          if (ws >= 0 && ws < p.Ws) colm |= 1u << kw;
+        }
+        for (int kh = 0; kh < p.KH; ++kh)
+          if ((rowm >> kh) & 1u) mask |= colm << (kh * p.KW);
+      }
     }
     a_off[i] = off;
     a_mask[i] = mask;
@@ -249,6 +286,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  MXDET_CS(1);
 
   const int frow = lane & 15, fq = lane >> 4;
   if constexpr (HP) {
@@ -383,6 +421,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     // ... in every wave; the same barrier says every wave is done reading the buffer refilled next
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef MXDET_CONV_STAMP
+    if (kt == 0) MXDET_CS(2);
+#endif
     // Software pipeline inside the step: the fragment reads of BOTH 32-deep halves are issued first (their LDS
     // latency overlaps the address math / DMA issue of the next stage), then the 2*MT*NT MFMAs run back to back.
     const uint16_t* sa = smem + cur * STAGE;
@@ -429,8 +470,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
   }
+  MXDET_CS(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail loads before LDS is re-used
   __syncthreads();
+  MXDET_CS(4);
 
   // ---- epilogue ---------------------------------------------------------------------------------
   float* ep = (float*)smem_raw + wid * 32 * EP_STRIDE;
@@ -527,13 +570,21 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
       }
       uint4 o;
-      o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-      o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-      o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
-      o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      o.z = pack_bf16x2(v[4], v[5]);
+      o.w = pack_bf16x2(v[6], v[7]);
       if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
     }
   }
+#ifdef MXDET_CONV_STAMP
+  if (cs_on) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    cs[5] = __builtin_amdgcn_s_memtime();
+    if (lane == 0)
+      for (int k = 0; k < 6; ++k) g_conv_stamp[blockIdx.x == 0 ? 0 : 1][k] = cs[k];
+  }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
@@ -662,6 +713,9 @@ static int launch(ConvP& p, hipStream_t s) {
     case 15: return launch_cfg<256, 256, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 128x64 per wave, 128 KiB
     case 16: return launch_cfg<256, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 64x64 per wave, 96 KiB
     case 17: return launch_cfg<256, 128, 2, 2, 2, DGRAD>(p, s);   // 4 waves, 128x64 per wave, 96 KiB
+    case 18: return launch_cfg<64, 64, 2, 2, 5, DGRAD>(p, s);     // 80 KiB: deep ring for grids of <= 2 workgroups per CU
+    case 19: return launch_cfg<64, 64, 2, 2, 4, DGRAD>(p, s);     // 64 KiB
+    case 26: return launch_cfg<64, 128, 2, 2, 5, DGRAD>(p, s);    // 120 KiB: one workgroup per CU, four stages in flight
     // half-stage pipeline (NS = 1) variants
     case 20: return launch_cfg<64, 64, 2, 2, 1, DGRAD>(p, s);
     case 21: return launch_cfg<64, 128, 2, 2, 1, DGRAD>(p, s);
@@ -732,6 +786,12 @@ static int validate(const mxdet_conv_desc_t* d, const char* who) {
 }  // namespace mxdet
 
 using namespace mxdet;
+
+#ifdef MXDET_CONV_STAMP
+extern "C" int mxdet_debug_read_conv_stamps(unsigned long long* out /* host, 16 */) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamp), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" int mxdet_debug_force_conv_cfg(int32_t cfg) {
   g_force_cfg = cfg;

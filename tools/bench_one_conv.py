@@ -54,3 +54,13 @@ b.record(); b.synchronize()
 t = a.elapsed_time(b) * 1e-3 / reps
 fl = 2.0 * N * Ho * Wo * Cout * K * K * Cin
 print("%s N%d %dx%d Cin%d Cout%d k%d s%d cfg%d: %.1f us  %.1f TFLOP/s" % (kind, N, H, W, Cin, Cout, K, s, cfg, t * 1e6, fl / t / 1e12))
+
+lib = _lib.load()
+if hasattr(lib, "mxdet_debug_read_conv_stamps"):
+    import ctypes as C
+    buf = (C.c_uint64 * 16)()
+    lib.mxdet_debug_read_conv_stamps(buf)
+    for b in range(2):
+        v = list(buf[b * 8:b * 8 + 6])
+        names = ["geometry", "first stage landed", "K loop", "drain+barrier", "epilogue"]
+        print("  block %s: " % ("0" if b == 0 else "300") + "  ".join("%s %d" % (n, v[i + 1] - v[i]) for i, n in enumerate(names)) + "  total %d cycles" % (v[5] - v[0]))
