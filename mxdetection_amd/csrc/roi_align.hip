@@ -190,16 +190,25 @@ struct RoiTab {                        // per roi
   unsigned char vy[kRoiMaxSamples], vx[kRoiMaxSamples];
 };
 
-__global__ void roi_bwd_tab_kernel(FeatPyr f, const float* __restrict__ rois, const int32_t* __restrict__ levels,
-                                   long long R, int PH, int PW, int sr, RoiTab* __restrict__ tab) {
-  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+struct RoiBox { int n, lvl, ylo, yhi, xlo, xhi, pad0, pad1; };   // the part of RoiTab the list builders scan: compact (32 B)
+
+// One WAVE per roi: lanes 0..31 compute row sample `lane`, lanes 32..63 column sample `lane - 32` (one thread per roi
+// walked 28 samples in a serial loop: 16 waves on the whole chip, 73 us); the bounding box is a butterfly min / max.
+__global__ void __launch_bounds__(64)
+roi_bwd_tab_kernel(FeatPyr f, const float* __restrict__ rois, const int32_t* __restrict__ levels,
+                   long long R, int PH, int PW, int sr, RoiTab* __restrict__ tab, RoiBox* __restrict__ box) {
+  const long long r = (long long)blockIdx.x;
+  const int lane = threadIdx.x;
   if (r >= R) return;
   const RoiGeom g = roi_geom(f, rois, levels, r, PH, PW, sr);
   RoiTab& t = tab[r];
-  t.n = g.batch; t.lvl = g.lvl;
-  int ylo = 1 << 30, yhi = -1, xlo = 1 << 30, xhi = -1;
-  for (int ph = 0; ph < PH; ++ph)
-    for (int iy = 0; iy < g.gh; ++iy) {
+  const bool isx = lane >= 32;
+  const int s = lane & 31;
+  const int NS = isx ? PW * g.gw : PH * g.gh;
+  int lo = 1 << 30, hi = -1;
+  if (s < NS) {
+    if (!isx) {
+      const int ph = s / g.gh, iy = s - ph * g.gh;
       float y = g.start_h + (float)ph * g.bin_h;
       y = y + (((float)iy + 0.5f) * g.bin_h) / (float)g.gh;
       const Taps tp = bilinear_taps(y, 0.0f, g.H, g.W);       // the row part does not depend on x
@@ -208,12 +217,10 @@ __global__ void roi_bwd_tab_kernel(FeatPyr f, const float* __restrict__ rois, co
       float yy = y <= 0.0f ? 0.0f : y;
       if ((int)yy >= g.H - 1) yy = (float)(g.H - 1);
       const float lyv = yy - (float)tp.yl, hyv = 1.0f - lyv;
-      const int s = ph * g.gh + iy;
       t.yl[s] = (short)tp.yl; t.yh[s] = (short)tp.yh; t.hy[s] = hyv; t.ly[s] = lyv; t.vy[s] = vy ? 1 : 0;
-      if (vy) { ylo = tp.yl < ylo ? tp.yl : ylo; yhi = tp.yh > yhi ? tp.yh : yhi; }
-    }
-  for (int pw = 0; pw < PW; ++pw)
-    for (int ix = 0; ix < g.gw; ++ix) {
+      if (vy) { lo = tp.yl; hi = tp.yh; }
+    } else {
+      const int pw = s / g.gw, ix = s - pw * g.gw;
       float x = g.start_w + (float)pw * g.bin_w;
       x = x + (((float)ix + 0.5f) * g.bin_w) / (float)g.gw;
       const Taps tp = bilinear_taps(0.0f, x, g.H, g.W);
@@ -221,11 +228,25 @@ __global__ void roi_bwd_tab_kernel(FeatPyr f, const float* __restrict__ rois, co
       float xx = x <= 0.0f ? 0.0f : x;
       if ((int)xx >= g.W - 1) xx = (float)(g.W - 1);
       const float lxv = xx - (float)tp.xl, hxv = 1.0f - lxv;
-      const int s = pw * g.gw + ix;
       t.xl[s] = (short)tp.xl; t.xh[s] = (short)tp.xh; t.hx[s] = hxv; t.lx[s] = lxv; t.vx[s] = vx ? 1 : 0;
-      if (vx) { xlo = tp.xl < xlo ? tp.xl : xlo; xhi = tp.xh > xhi ? tp.xh : xhi; }
+      if (vx) { lo = tp.xl; hi = tp.xh; }
     }
-  t.ylo = ylo; t.yhi = yhi; t.xlo = xlo; t.xhi = xhi;
+  }
+  // min / max inside each 32-lane half (rows | columns)
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const int olo = __shfl_xor(lo, d), ohi = __shfl_xor(hi, d);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  const int xlo = __shfl(lo, 32), xhi = __shfl(hi, 32);
+  if (lane == 0) {
+    t.n = g.batch; t.lvl = g.lvl;
+    t.ylo = lo; t.yhi = hi; t.xlo = xlo; t.xhi = xhi;
+    RoiBox bx;
+    bx.n = g.batch; bx.lvl = g.lvl; bx.ylo = lo; bx.yhi = hi; bx.xlo = xlo; bx.xhi = xhi; bx.pad0 = 0; bx.pad1 = 0;
+    box[r] = bx;
+  }
 }
 
 struct RoiRows {                       // row r of level l, image n has id row0[l] + n * H[l] + r
@@ -235,7 +256,7 @@ struct RoiRows {                       // row r of level l, image n has id row0[
 
 // one wave per pyramid row: the rois whose valid samples touch it, in ascending index order (ballot compaction)
 __global__ void __launch_bounds__(64)
-roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiTab* __restrict__ tab, int R,
+roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiBox* __restrict__ box, int R,
                     unsigned short* __restrict__ row_list, int* __restrict__ row_count) {
   const int row = (int)blockIdx.x, lane = threadIdx.x;
   if (row >= rr.rows_total) return;
@@ -249,7 +270,7 @@ roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiTab* __restrict__ tab, int R
     const int r = r0 + lane;
     bool hit = false;
     if (r < R) {
-      const RoiTab& t = tab[r];
+      const RoiBox t = box[r];            // 32 B per lane, consecutive lanes consecutive rois
       hit = t.lvl == l && t.n == n && y >= t.ylo && y <= t.yhi && t.xlo <= t.xhi;
     }
     const unsigned long long m = __ballot(hit);
@@ -264,7 +285,7 @@ roi_bwd_rows_kernel(FeatPyr f, RoiRows rr, const RoiTab* __restrict__ tab, int R
 // hit this row / this segment come out of two ballots, and the loops walk the set bits with v_readlane -- no memory
 // latency inside them.
 __global__ void __launch_bounds__(64)
-roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restrict__ tab, int R,
+roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restrict__ tab, const RoiBox* __restrict__ box, int R,
                             const unsigned short* __restrict__ row_list, const int* __restrict__ row_count,
                             int PH, int PW, int sr, const uint16_t* __restrict__ gout, int accumulate) {
   int l = 0;
@@ -298,7 +319,7 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
      // on the finest level) get their tables loaded
      const int kk = base + lane;
      const int rk = kk < cnt ? list[kk] : 0;
-     const bool hitk = kk < cnt && tab[rk].xhi >= x0 && tab[rk].xlo <= x1;
+     const bool hitk = kk < cnt && box[rk].xhi >= x0 && box[rk].xlo <= x1;
      unsigned long long mr = __ballot(hitk);
      while (mr) {
       const int kb = __ffsll((long long)mr) - 1;
@@ -436,7 +457,8 @@ extern "C" int mxdet_roi_align_bwd(const mxdet_feat_pyramid_t* f, int32_t N, int
   return check_launch("roi_align_bwd");
 }
 
-static size_t roi_gather_carve(const FeatPyr& d, long long R, RoiRows* rr, size_t* off_tab, size_t* off_list, size_t* off_cnt) {
+static size_t roi_gather_carve(const FeatPyr& d, long long R, RoiRows* rr, size_t* off_tab, size_t* off_list, size_t* off_cnt,
+                               size_t* off_box) {
   int rows = 0, blocks = 0;
   for (int l = 0; l < d.num_levels; ++l) {
     rr->row0[l] = rows;
@@ -451,6 +473,7 @@ static size_t roi_gather_carve(const FeatPyr& d, long long R, RoiRows* rr, size_
   *off_tab = off; off = align_up(off + (size_t)R * sizeof(RoiTab), 256);
   *off_list = off; off = align_up(off + (size_t)rows * (size_t)R * sizeof(unsigned short), 256);
   *off_cnt = off; off = align_up(off + (size_t)rows * sizeof(int), 256);
+  *off_box = off; off = align_up(off + (size_t)R * sizeof(RoiBox), 256);
   return off;
 }
 
@@ -460,8 +483,8 @@ extern "C" size_t mxdet_roi_align_bwd_gather_workspace_bytes(const mxdet_feat_py
   memset(&d, 0, sizeof(d));
   d.num_levels = f->num_levels; d.N = N;
   for (int l = 0; l < f->num_levels; ++l) { d.H[l] = f->H[l]; d.W[l] = f->W[l]; }
-  RoiRows rr; size_t a, b, c;
-  return roi_gather_carve(d, R, &rr, &a, &b, &c);
+  RoiRows rr; size_t a, b, c, e;
+  return roi_gather_carve(d, R, &rr, &a, &b, &c, &e);
 }
 
 extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
@@ -479,21 +502,22 @@ extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t
   for (int l = 0; l < d.num_levels; ++l)
     MXDET_REQUIRE(d.H[l] < 32768 && d.W[l] < 32768, MXDET_ESHAPE, "roi_align_bwd_gather: level %d too large", l);
   MXDET_REQUIRE(rois && levels && grad_out, MXDET_EINVAL, "roi_align_bwd_gather: null pointer");
-  RoiRows rr; size_t o_tab, o_list, o_cnt;
-  const size_t need = roi_gather_carve(d, R > 0 ? R : 1, &rr, &o_tab, &o_list, &o_cnt);
+  RoiRows rr; size_t o_tab, o_list, o_cnt, o_box;
+  const size_t need = roi_gather_carve(d, R > 0 ? R : 1, &rr, &o_tab, &o_list, &o_cnt, &o_box);
   MXDET_REQUIRE(workspace && workspace_bytes >= need, MXDET_EWORKSPACE, "roi_align_bwd_gather: workspace %zu < %zu",
                 workspace_bytes, need);
   hipStream_t s = as_stream(stream);
   RoiTab* tab = (RoiTab*)((char*)workspace + o_tab);
   unsigned short* list = (unsigned short*)((char*)workspace + o_list);
   int* cnt = (int*)((char*)workspace + o_cnt);
+  RoiBox* box = (RoiBox*)((char*)workspace + o_box);
   if (R > 0)
-    hipLaunchKernelGGL(roi_bwd_tab_kernel, dim3((unsigned)ceil_div<long long>(R, 64)), dim3(64), 0, s, d, rois, levels,
-                       (long long)R, PH, PW, sampling_ratio, tab);
-  hipLaunchKernelGGL(roi_bwd_rows_kernel, dim3(rr.rows_total), dim3(64), 0, s, d, rr, (const RoiTab*)tab,
+    hipLaunchKernelGGL(roi_bwd_tab_kernel, dim3((unsigned)R), dim3(64), 0, s, d, rois, levels, (long long)R, PH, PW,
+                       sampling_ratio, tab, box);
+  hipLaunchKernelGGL(roi_bwd_rows_kernel, dim3(rr.rows_total), dim3(64), 0, s, d, rr, (const RoiBox*)box,
                      (int)R, list, cnt);
   hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)rr.block0[d.num_levels]), dim3(64), 0, s, d, rr, C,
-                     (const RoiTab*)tab, (int)R, (const unsigned short*)list, (const int*)cnt, PH, PW, sampling_ratio,
-                     grad_out, accumulate);
+                     (const RoiTab*)tab, (const RoiBox*)box, (int)R, (const unsigned short*)list, (const int*)cnt, PH, PW,
+                     sampling_ratio, grad_out, accumulate);
   return check_launch("roi_align_bwd_gather");
 }
