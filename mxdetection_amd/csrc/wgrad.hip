@@ -41,7 +41,7 @@ wgrad_kernel(WgradP p) {
 // under hipGraph replay); slab addresses are offsets from the workspace passed at launch.
 
 template <int BKP, int NS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 2 ? 4 : (NS == 3 ? 3 : 2), 4)))
 wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace, int block_off,
                      int total) {
   // Persistent form: the grid may be smaller than the tile list (gridDim.x a multiple of 8 keeps logical tile -> XCD),
@@ -572,8 +572,20 @@ extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int3
   for (int off = 0; off < grid_wgrad; off += chunk) {
     const int cnt = grid_wgrad - off < chunk ? grid_wgrad - off : chunk;
     const int grid = persist > 0 && persist < cnt ? persist : cnt;
-    hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
-                       (unsigned char*)workspace, off, off + cnt);
+    // ring depth: 2 stages (32 KiB, 4 workgroups per CU), 3 (48 KiB, 3 per CU) or 4 (64 KiB, 2 per CU)
+    switch ((int)tuning(MXDET_TUNE_WG_NS)) {
+      case 3:
+        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 3>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
+                           (unsigned char*)workspace, off, off + cnt);
+        break;
+      case 4:
+        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 4>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
+                           (unsigned char*)workspace, off, off + cnt);
+        break;
+      default:
+        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
+                           (unsigned char*)workspace, off, off + cnt);
+    }
   }
   if (grid_reduce > 0)
     hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)grid_reduce), dim3(256), 0, s,

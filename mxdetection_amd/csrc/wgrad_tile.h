@@ -154,8 +154,13 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
       const bool yok = mok && c_yok[i];
       const bool xok = mok && c_xok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
       const int offx = ((c_img[i] * p.H + hi) * p.W + wi) * p.Cin + c_chx[i];
+#ifdef MXDET_WG_L2TEST   /* diagnostic: every workgroup streams the same 1 MiB of dy / x (wrong results, timing only) */
+      const unsigned vy = yok ? (2u * (unsigned)c_offy[i]) & 0xfffffu : kDmaOob;
+      const unsigned vx = xok ? (2u * (unsigned)offx) & 0xfffffu : kDmaOob;
+#else
       const unsigned vy = yok ? 2u * (unsigned)c_offy[i] : kDmaOob;
       const unsigned vx = xok ? 2u * (unsigned)offx : kDmaOob;
+#endif
 #ifndef MXDET_ABL_NOLOAD
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lptr_t)(smem[buf][0] + (wid * GI + i) * 1024), 16, (int)vy, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(smem[buf][1] + (wid * GI + i) * 1024), 16, (int)vx, 0, 0, 0);

@@ -25,7 +25,7 @@ def main():
     torch.cuda.synchronize()
     agg = {}
     REPS = 8
-    for family, flops, fn, a, kw in timer.log:
+    for family, flops, fn, a, kw, _shape in timer.log:
         t = bench.ConvTimer.time_launch(fn, a, kw, REPS)
         plan = a[0] if a and hasattr(a[0], "grid") or (a and hasattr(a[0], "grid_wgrad")) else None
         if plan is not None:     # grouped launch: (layers in the group, -, -, 0, 0)
