@@ -127,8 +127,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
   const int HW = p.Ho * p.Wo;
   const int d_img = BKP / HW, d_rem = BKP - d_img * HW;
   const int d_ho = d_rem / p.Wo, d_wo = d_rem - d_ho * p.Wo;
-  int c_img[GI], c_ho[GI], c_wo[GI], c_m[GI], c_offy[GI], c_chx[GI];
+  // (the K loop is VALU-issue bound -- four waves per SIMD share one vector issue port with their MFMAs -- so the
+  // per-step bookkeeping is kept to adds, compares and selects: the source offset advances by constants picked by the
+  // two carries instead of being recomputed with multiplies)
+  int c_ho[GI], c_wo[GI], c_m[GI], c_offy[GI], c_offx[GI];
   bool c_yok[GI], c_xok[GI];
+  const int stepx0 = ((d_img * p.H + d_ho * p.stride) * p.W + d_wo * p.stride) * p.Cin;
+  const int stepx_w = (p.stride * p.W - p.Wo * p.stride) * p.Cin;
+  const int stepx_h = (p.H * p.W - p.Ho * p.stride * p.W) * p.Cin;
 #pragma unroll
   for (int i = 0; i < GI; ++i) {
     int row = (wid * GI + i) * 4 + lrow;
@@ -136,12 +142,13 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
     int chunk = ((((lslot >> 1) ^ f) << 1) | (lslot & 1)) * 8;     // first channel of this lane's 16 bytes
     int m = step0 * BKP + row;
     c_m[i] = m;
-    c_img[i] = m / HW;
-    int rem = m - c_img[i] * HW;
+    const int img = m / HW;
+    int rem = m - img * HW;
     c_ho[i] = rem / p.Wo;
     c_wo[i] = rem - c_ho[i] * p.Wo;
     c_offy[i] = m * p.Cout + co0 + chunk;
-    c_chx[i] = ci0 + chunk;
+    // element offset of the tap's source pixel (may lie outside the map: then the lane reads nothing)
+    c_offx[i] = ((img * p.H + c_ho[i] * p.stride - p.pad + kh) * p.W + c_wo[i] * p.stride - p.pad + kw) * p.Cin + ci0 + chunk;
     c_yok[i] = (co0 + chunk) < p.Cout;
     c_xok[i] = (ci0 + chunk) < p.Cin;
   }
@@ -153,7 +160,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
       const int hi = c_ho[i] * p.stride - p.pad + kh, wi = c_wo[i] * p.stride - p.pad + kw;
       const bool yok = mok && c_yok[i];
       const bool xok = mok && c_xok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-      const int offx = ((c_img[i] * p.H + hi) * p.W + wi) * p.Cin + c_chx[i];
+      const int offx = c_offx[i];
 #ifdef MXDET_WG_L2TEST   /* diagnostic: every workgroup streams the same 1 MiB of dy / x (wrong results, timing only) */
       const unsigned vy = yok ? (2u * (unsigned)c_offy[i]) & 0xfffffu : kDmaOob;
       const unsigned vx = xok ? (2u * (unsigned)offx) & 0xfffffu : kDmaOob;
@@ -171,12 +178,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
       c_m[i] += BKP;
       c_offy[i] += stepy;
       c_wo[i] += d_wo;
-      int cw = c_wo[i] >= p.Wo ? 1 : 0;
+      const bool cw = c_wo[i] >= p.Wo;
       c_wo[i] -= cw ? p.Wo : 0;
-      c_ho[i] += d_ho + cw;
-      int ch = c_ho[i] >= p.Ho ? 1 : 0;
+      c_ho[i] += d_ho + (cw ? 1 : 0);
+      const bool ch = c_ho[i] >= p.Ho;
       c_ho[i] -= ch ? p.Ho : 0;
-      c_img[i] += d_img + ch;
+      c_offx[i] += stepx0 + (cw ? stepx_w : 0) + (ch ? stepx_h : 0);
     }
   };
 
@@ -221,26 +228,25 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
     // four reads are still in flight under the first eight MFMAs. The fences name the registers they release.
     const unsigned sbase = smem_addr + (unsigned)cur * (2u * BKP * 256u);
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-    s16x4_t ylo[4], yhi[4], xlo[4], xhi[4];
+    s16x8_t bx[4], ay[4];
+    // (each fragment is packed right where its two reads are issued: with the reads hoisted into arrays first the
+    // compiler copied every half into place -- 64 v_mov per step on a loop that is vector-issue bound)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned ad = sbase + (unsigned)(BKP * 256) + offx[j];
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[j]) : "v"(ad));
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(xhi[j]) : "v"(ad));
+      s16x4_t lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+      bx[j] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned ad = sbase + offy[i];
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[i]) : "v"(ad));
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(yhi[i]) : "v"(ad));
+      s16x4_t lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+      ay[i] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
-    s16x8_t bx[4], ay[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      bx[j] = (s16x8_t){xlo[j][0], xlo[j][1], xlo[j][2], xlo[j][3], xhi[j][0], xhi[j][1], xhi[j][2], xhi[j][3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      ay[i] = (s16x8_t){ylo[i][0], ylo[i][1], ylo[i][2], ylo[i][3], yhi[i][0], yhi[i][1], yhi[i][2], yhi[i][3]};
     asm volatile("s_waitcnt lgkmcnt(4)"
                  : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]), "+v"(ay[0]), "+v"(ay[1]));
 #pragma unroll
