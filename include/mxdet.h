@@ -186,13 +186,24 @@ int mxdet_roi_align_bwd(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, con
                         int32_t sampling_ratio, const uint16_t* grad_out, mxdet_stream_t stream);
 /* bwd, gather form: deterministic, no atomics, no fp32 accumulators. f->feat[l] are the bf16 [N,H,W,C] GRADIENT maps
  * themselves: every pixel is written (accumulate = 0) or added to (accumulate = 1, one bf16 rounding of the sum).
- * Per pixel the contributions are summed in fp32 in the order (roi index, row sample, upper before lower row tap,
- * column sample, left before right tap). Requires sampling_ratio > 0 and at most 32 samples per axis. */
+ * Per pixel the contributions are summed in fp32 in a fixed order: roi index ascending; inside a roi the bilinear
+ * weights are collapsed per pooling bin (they are separable), row bins before column bins -- bit-reproducible run to
+ * run, last-bit different from the sample-by-sample order of mxdet_roi_align_bwd. Requires sampling_ratio > 0 and at
+ * most 32 samples per axis. The per-roi records the gather reads depend only on the rois: `_prepare` writes them into
+ * the workspace (it can be issued as soon as the rois exist, e.g. in the forward pass) and `_prepared` is the gather
+ * without that pass; the plain call does both. */
 size_t mxdet_roi_align_bwd_gather_workspace_bytes(const mxdet_feat_pyramid_t* f, int32_t N, int64_t R);
 int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
                                const int32_t* levels, int64_t R, int32_t PH, int32_t PW, int32_t sampling_ratio,
                                const uint16_t* grad_out, int32_t accumulate, void* workspace, size_t workspace_bytes,
                                mxdet_stream_t stream);
+int mxdet_roi_align_bwd_gather_prepare(const mxdet_feat_pyramid_t* f, int32_t N, const float* rois,
+                                       const int32_t* levels, int64_t R, int32_t PH, int32_t PW, int32_t sampling_ratio,
+                                       void* workspace, size_t workspace_bytes, mxdet_stream_t stream);
+int mxdet_roi_align_bwd_gather_prepared(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
+                                        const int32_t* levels, int64_t R, int32_t PH, int32_t PW, int32_t sampling_ratio,
+                                        const uint16_t* grad_out, int32_t accumulate, void* workspace,
+                                        size_t workspace_bytes, mxdet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * core/loss (README.md:19)

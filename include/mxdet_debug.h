@@ -38,7 +38,9 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_WGB_MINPX 9    /* ... only for items with at least this many output pixels (default 100000) */
 #define MXDET_TUNE_TAIL 10        /* conv: tiles of the rows left over by the 256x256 rounds: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
 #define MXDET_TUNE_WG_NS 11       /* grouped wgrad (128x128 tiles): LDS-DMA ring depth 2, 3 or 4 */
-#define MXDET_TUNE_COUNT 12
+#define MXDET_TUNE_ROI_TABLE 12   /* RoIAlign backward (gather): 1 = the three-kernel table form instead of the segment form */
+#define MXDET_TUNE_ROI_ROWS 13    /* RoIAlign backward, segment form: rows per tile on maps with >= 64 rows (default 2) */
+#define MXDET_TUNE_COUNT 14
 int mxdet_debug_set_tuning(int32_t which, int64_t value);
 
 #ifdef __cplusplus

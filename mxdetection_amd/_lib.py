@@ -99,6 +99,10 @@ SIGNATURES = {
     "mxdet_roi_align_bwd_gather_workspace_bytes": (c_sz, [P(FeatPyramidT), c_i32, c_i64]),
     "mxdet_roi_align_bwd_gather": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp,
                                            c_i32, c_vp, c_sz, c_vp]),
+    "mxdet_roi_align_bwd_gather_prepare": (c_i32, [P(FeatPyramidT), c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
+                                                   c_vp, c_sz, c_vp]),
+    "mxdet_roi_align_bwd_gather_prepared": (c_i32, [P(FeatPyramidT), c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
+                                                    c_vp, c_i32, c_vp, c_sz, c_vp]),
     "mxdet_smooth_l1_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "mxdet_smooth_l1_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_i32, c_vp, c_vp]),
     "mxdet_loss_workspace_bytes": (c_sz, [c_i64]),
@@ -164,7 +168,7 @@ SIGNATURES = {
 DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
                  "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
 TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "WGB_ENABLE": 6,
-               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9, "TAIL": 10, "WG_NS": 11}
+               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13}
 
 _lib = None
 

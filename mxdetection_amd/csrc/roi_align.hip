@@ -405,6 +405,300 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
   }
 }
 
+// ---- backward, segment form (default) ----------------------------------------------------------------------------------
+// Two launches: a per-roi box pass (R threads) and the gather. A gather workgroup owns a tile of `rows_per_wg` pyramid
+// rows x up to 8 consecutive 8-pixel segments (one WAVE per segment column; a lane owns 4 channels, 8 x 4 fp32 sums in
+// registers per row). It first builds, in LDS and in ascending roi order, the list of rois whose valid samples touch its
+// tile (one coalesced 32-B record per roi), then every wave walks the list once per row of the tile. Per (roi, row,
+// segment) hit the bilinear weights are collapsed per pooling bin -- they are separable:
+//     d[Y][X][c] += sum_ph ay(Y,ph) * sum_pw ax(X,pw) * dY[r][ph][pw][c],   ay(Y,ph) = sum of the row weights of bin ph's
+// samples on row Y (likewise ax) -- so the wave loads the <= 3 x PW bins it needs in ONE round of independent loads
+// (the sample-by-sample walk of the table form is one L2 round trip per sample pair), folds the rows
+// (T[pw] = sum_by ay * dY) and distributes T over its 8 pixels with the column weights (lane 32+s holds column sample
+// s; v_readlane hands them out as scalars). Fixed summation order (roi ascending, row bins, column bins): bit-
+// reproducible. The sums differ from the oracle's sample-by-sample order in the last bits (tolerance in the test).
+constexpr int kSegW = 8;          // pixels per wave
+constexpr int kSegWaves = 8;      // waves (segment columns) per workgroup
+constexpr int kSegChunk = 1024;   // rois per list round
+
+struct RoiSegGrid {
+  int block0[9];                  // first workgroup of level l
+  int chunks[8];                  // workgroups along a row
+  int segs_per_wg[8];             // segments each of them owns (<= kSegWaves)
+  int rows_per_wg[8];             // rows of a tile
+  int bands[8];                   // tiles along a column = ceil(H / rows_per_wg)
+};
+
+struct RoiSeg {                   // per roi, 32 B
+  int nl;                         // image | level << 16 (level 0xffff: no valid sample)
+  unsigned yy, xx;                // ylo | yhi << 16, xlo | xhi << 16: pixel bounding box of its valid samples
+  int r;
+  float start_h, bin_h, start_w, bin_w;
+};
+
+struct AxisSample { int lo, hi; float wlo, whi; bool valid; };
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// value of lane + 1 inside a 16-lane row (DPP row_shl:1; the last lane of a row reads 0): the two samples of a bin
+// never straddle a row, so this replaces a ds_bpermute round trip per weight
+__device__ __forceinline__ float lane_plus1(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x101, 0xf, 0xf, true));
+}
+
+// coordinate of sample s of an axis (bin = s / sr), exactly as the forward / the oracle computes it
+template <int SR>
+__device__ __forceinline__ float roi_axis_coord(float start, float bin, int s, int sr) {
+  const int b = SR ? s / SR : s / sr, i = s - b * (SR ? SR : sr);
+  float v = start + (float)b * bin;
+  return v + (((float)i + 0.5f) * bin) / (float)(SR ? SR : sr);
+}
+
+// the per-axis half of bilinear_taps
+__device__ __forceinline__ AxisSample roi_axis_sample(float v, int L) {
+  AxisSample a;
+  a.valid = !(v < -1.0f || v > (float)L);
+  if (v <= 0.0f) v = 0.0f;
+  int lo = (int)v;
+  if (lo >= L - 1) { a.hi = lo = L - 1; v = (float)lo; } else { a.hi = lo + 1; }
+  a.lo = lo;
+  a.whi = v - (float)lo;
+  a.wlo = 1.0f - a.whi;
+  return a;
+}
+
+// pixel range [lo, hi] touched by the valid samples of one axis (lo > hi: none)
+__device__ __forceinline__ void roi_axis_range(float start, float bin, int NS, int sr, int L, int* lo, int* hi) {
+  int s0 = 0, s1 = NS - 1;
+  while (s0 <= s1 && !roi_axis_sample(roi_axis_coord<0>(start, bin, s0, sr), L).valid) ++s0;
+  while (s1 >= s0 && !roi_axis_sample(roi_axis_coord<0>(start, bin, s1, sr), L).valid) --s1;
+  if (s0 > s1) { *lo = 1; *hi = 0; return; }
+  *lo = roi_axis_sample(roi_axis_coord<0>(start, bin, s0, sr), L).lo;
+  *hi = roi_axis_sample(roi_axis_coord<0>(start, bin, s1, sr), L).hi;
+}
+
+__global__ void __launch_bounds__(256)
+roi_bwd_box_kernel(FeatPyr f, const float* __restrict__ rois, const int32_t* __restrict__ levels, int R, int PH, int PW,
+                   int sr, RoiSeg* __restrict__ seg) {
+  const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= R) return;
+  const RoiGeom g = roi_geom(f, rois, levels, r, PH, PW, sr);
+  int ylo, yhi, xlo, xhi;
+  roi_axis_range(g.start_h, g.bin_h, PH * sr, sr, g.H, &ylo, &yhi);
+  roi_axis_range(g.start_w, g.bin_w, PW * sr, sr, g.W, &xlo, &xhi);
+  RoiSeg o;
+  const bool any = ylo <= yhi && xlo <= xhi;
+  o.nl = g.batch | ((any ? g.lvl : 0xffff) << 16);
+  o.yy = (unsigned)ylo | ((unsigned)yhi << 16);
+  o.xx = (unsigned)xlo | ((unsigned)xhi << 16);
+  o.r = r;
+  o.start_h = g.start_h; o.bin_h = g.bin_h; o.start_w = g.start_w; o.bin_w = g.bin_w;
+  seg[r] = o;
+}
+
+template <int PWT, int SR>        // PW <= PWT; SR = the sampling ratio when it is 2 (0: run-time value)
+__global__ void __launch_bounds__(kSegWaves * 64)
+roi_bwd_seg_kernel(FeatPyr f, RoiSegGrid gr, int C, const RoiSeg* __restrict__ seg, int R, int PH, int PW, int sr_,
+                   const uint16_t* __restrict__ gout, int accumulate) {
+  __shared__ unsigned e_xx[kSegChunk], e_yy[kSegChunk];   // the fields the walk scans, one word per lane
+  __shared__ int e_r[kSegChunk];
+  __shared__ float4 e_g[kSegChunk];                        // start_h, bin_h, start_w, bin_w
+  __shared__ int wcnt[kSegWaves];
+  __shared__ int s_cnt;
+  const int sr = SR ? SR : sr_;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int l = 0;
+  const int bid = (int)blockIdx.x;
+  while (l + 1 < f.num_levels && bid >= gr.block0[l + 1]) ++l;
+  const int rel = bid - gr.block0[l];
+  const int per_img = gr.bands[l] * gr.chunks[l];
+  const int n = rel / per_img, rem = rel - n * per_img;
+  const int band = rem / gr.chunks[l], chunk = rem - band * gr.chunks[l];
+  const int H = f.H[l], W = f.W[l];
+  const int Y0 = band * gr.rows_per_wg[l];
+  const int Y1 = (Y0 + gr.rows_per_wg[l] - 1 < H - 1) ? Y0 + gr.rows_per_wg[l] - 1 : H - 1;
+  const int spw = gr.segs_per_wg[l];
+  const int X0 = chunk * spw * kSegW;                                    // the workgroup's pixel span
+  const int X1 = (X0 + spw * kSegW - 1 < W - 1) ? X0 + spw * kSegW - 1 : W - 1;
+  const int x0 = X0 + wid * kSegW;                                       // this wave's segment column
+  const int x1 = (x0 + kSegW - 1 < W - 1) ? x0 + kSegW - 1 : W - 1;
+  const bool wave_live = wid < spw && x0 < W;
+  const int cb = (int)blockIdx.y * 256;
+  const bool live = cb + lane * 4 < C;
+  const int c0 = live ? cb + lane * 4 : 0;
+  const int NSY = PH * sr, NSX = PW * sr;
+  const float count = (float)(sr * sr);
+  const bool pow2 = ((sr * sr) & (sr * sr - 1)) == 0;
+  const float inv_count = 1.0f / count;
+  const int key = n | (l << 16);
+  const bool isx = lane >= 32;
+  const int s = lane & 31;
+
+  // A one-row tile keeps its sums in registers across list rounds and writes once; a multi-row tile writes every row
+  // at the end of each round (the host only makes multi-row tiles when all rois fit one round).
+  const bool multi_row = Y1 > Y0;
+  f32x2_t acc[kSegW][2];
+#pragma unroll
+  for (int j = 0; j < kSegW; ++j) { acc[j][0] = (f32x2_t){0.f, 0.f}; acc[j][1] = (f32x2_t){0.f, 0.f}; }
+  bool touched = false;
+  for (int rc = 0; rc < R; rc += kSegChunk) {
+    // ---- the list of this round: rois rc .. rc+kSegChunk-1 that touch the tile, ascending ----
+    __syncthreads();                      // every wave is done with the previous round's list
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const int rend = rc + kSegChunk < R ? rc + kSegChunk : R;
+    for (int rb = rc; rb < rend; rb += kSegWaves * 64) {
+      const int r = rb + tid;
+      bool hit = false;
+      RoiSeg t;
+      if (r < rend) {
+        t = seg[r];
+        hit = t.nl == key && (int)(t.yy >> 16) >= Y0 && (int)(t.yy & 0xffffu) <= Y1 &&
+              (int)(t.xx >> 16) >= X0 && (int)(t.xx & 0xffffu) <= X1;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wcnt[wid] = __popcll(m);
+      __syncthreads();
+      int base = s_cnt;
+#pragma unroll
+      for (int w = 0; w < kSegWaves; ++w) base += (w < wid) ? wcnt[w] : 0;
+      if (hit) {
+        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+        e_xx[k] = t.xx; e_yy[k] = t.yy; e_r[k] = t.r;
+        e_g[k] = make_float4(t.start_h, t.bin_h, t.start_w, t.bin_w);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int tt = s_cnt;
+#pragma unroll
+        for (int w = 0; w < kSegWaves; ++w) tt += wcnt[w];
+        s_cnt = tt;
+      }
+      __syncthreads();
+    }
+    const int cnt = s_cnt;
+    if (!wave_live) continue;             // (the barriers above are reached by every wave: `continue` re-enters the loop)
+    const bool first_round = rc == 0, last_round = rend == R;
+
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      if (multi_row) {
+#pragma unroll
+        for (int j = 0; j < kSegW; ++j) { acc[j][0] = (f32x2_t){0.f, 0.f}; acc[j][1] = (f32x2_t){0.f, 0.f}; }
+        touched = false;
+      }
+      // ---- walk the list ----
+      for (int base = 0; base < cnt; base += 64) {
+        const int kk = base + lane;
+        unsigned xk = 0u, yk = 0u;
+        if (kk < cnt) { xk = e_xx[kk]; yk = e_yy[kk]; }
+        const bool hitk = kk < cnt && (int)(xk >> 16) >= x0 && (int)(xk & 0xffffu) <= x1 &&
+                          (int)(yk >> 16) >= Y && (int)(yk & 0xffffu) <= Y;
+        unsigned long long mr = __ballot(hitk);
+        while (mr) {
+          const int kb = base + __ffsll((long long)mr) - 1;
+          mr &= mr - 1;
+          const int r = e_r[kb];
+          const float4 gq = e_g[kb];
+          const float gsh = gq.x, gbh = gq.y, gsw = gq.z, gbw = gq.w;
+          // lane s < 32: row sample s; lane 32 + s: column sample s
+          const float v = roi_axis_coord<SR>(isx ? gsw : gsh, isx ? gbw : gbh, s, sr);
+          const AxisSample a = roi_axis_sample(v, isx ? W : H);
+          const bool ok = a.valid && s < (isx ? NSX : NSY);
+          const unsigned long long mb = __ballot(ok && !isx && (a.lo == Y || a.hi == Y));
+          const unsigned long long mc = __ballot(ok && isx && a.hi >= x0 && a.lo <= x1);
+          if (mb == 0ull || mc == 0ull) continue;
+          touched = true;
+          // per-bin weights: the first lane of each bin's sr samples gets the bin's sum
+          const float wy = (ok && !isx) ? ((a.lo == Y ? a.wlo : 0.0f) + (a.hi == Y ? a.whi : 0.0f)) : 0.0f;
+          float ayb = wy;
+          if (SR == 2) ayb = ayb + lane_plus1(wy);
+          else for (int i = 1; i < sr; ++i) ayb = ayb + __shfl_down(wy, i);
+          if (pow2) ayb = ayb * inv_count;               // a power-of-two count divides exactly as a multiplication
+          float axb[kSegW];
+#pragma unroll
+          for (int j = 0; j < kSegW; ++j) {
+            const int X = x0 + j;
+            const float wx = (ok && isx) ? ((a.lo == X ? a.wlo : 0.0f) + (a.hi == X ? a.whi : 0.0f)) : 0.0f;
+            float t = wx;
+            if (SR == 2) t = t + lane_plus1(wx);
+            else for (int i = 1; i < sr; ++i) t = t + __shfl_down(wx, i);
+            axb[j] = t;
+          }
+          const int pb0 = (__ffsll((long long)mb) - 1) / sr, pb1 = (63 - __clzll((long long)mb)) / sr;
+          const int pc0 = (__ffsll((long long)mc) - 1 - 32) / sr, pc1 = (63 - __clzll((long long)mc) - 32) / sr;
+          const uint16_t* g0 = gout + (size_t)r * PH * PW * C + c0;
+#ifdef MXDET_ROI_ABL_NOMATH
+          acc[0][0][0] += ayb + axb[0] + axb[7] + (float)(pb0 + pb1 + pc0 + pc1) + (float)g0[0];
+          continue;
+#endif
+          for (int b0 = pb0; b0 <= pb1; b0 += 3) {
+            uint2 g[3][PWT];
+            float wyb[3];
+#pragma unroll
+            for (int by = 0; by < 3; ++by) {
+              const bool rowok = b0 + by <= pb1;
+              const int ph = rowok ? b0 + by : pb1;
+              wyb[by] = rowok ? __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ayb), ph * sr)) : 0.0f;
+#pragma unroll
+              for (int pw = 0; pw < PWT; ++pw) {
+                g[by][pw] = make_uint2(0u, 0u);
+#ifndef MXDET_ROI_ABL_NOLOAD
+                if (rowok && pw >= pc0 && pw <= pc1) g[by][pw] = *(const uint2*)(g0 + (size_t)(ph * PW + pw) * C);
+#else
+                if (rowok && pw >= pc0 && pw <= pc1) g[by][pw] = make_uint2((unsigned)r, (unsigned)ph);
+#endif
+              }
+            }
+#pragma unroll
+            for (int pw = 0; pw < PWT; ++pw) {
+              if (pw < pc0 || pw > pc1) continue;        // wave-uniform
+              // (explicit fused multiply-adds, two channels per instruction: this file is built without contraction for
+              // the bit-exact forward, and the walk is VALU-issue bound)
+              f32x2_t T0 = {0.f, 0.f}, T1 = {0.f, 0.f};
+#pragma unroll
+              for (int by = 0; by < 3; ++by) {
+                f32x2_t a0 = {__uint_as_float(g[by][pw].x << 16), __uint_as_float(g[by][pw].x & 0xffff0000u)};
+                f32x2_t a1 = {__uint_as_float(g[by][pw].y << 16), __uint_as_float(g[by][pw].y & 0xffff0000u)};
+                if (!pow2) { a0[0] /= count; a0[1] /= count; a1[0] /= count; a1[1] /= count; }
+                const f32x2_t wv = {wyb[by], wyb[by]};
+                T0 = __builtin_elementwise_fma(wv, a0, T0);
+                T1 = __builtin_elementwise_fma(wv, a1, T1);
+              }
+#pragma unroll
+              for (int j = 0; j < kSegW; ++j) {
+                const float w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(axb[j]), 32 + pw * sr));
+                const f32x2_t wv = {w, w};
+                acc[j][0] = __builtin_elementwise_fma(wv, T0, acc[j][0]);
+                acc[j][1] = __builtin_elementwise_fma(wv, T1, acc[j][1]);
+              }
+            }
+          }
+        }
+      }
+      // ---- write row Y: a one-row tile after its last round, a multi-row tile every round (rounds after the first add) ----
+      if (!live || (!multi_row && !last_round)) continue;
+      const bool add = accumulate || (multi_row && !first_round);
+      if (add && !touched) continue;                  // nothing to add: leave the map as it is (no read-modify-write)
+      uint16_t* out = (uint16_t*)f.feat[l] + ((size_t)(n * H + Y) * W + x0) * C + c0;
+#pragma unroll
+      for (int j = 0; j < kSegW; ++j) {
+        if (x0 + j >= W) break;
+        uint16_t* o = out + (size_t)j * C;
+        float v[4] = {acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]};
+        if (add) {
+          const uint2 ee = *(const uint2*)o;
+          v[0] = v[0] + __uint_as_float(ee.x << 16); v[1] = v[1] + __uint_as_float(ee.x & 0xffff0000u);
+          v[2] = v[2] + __uint_as_float(ee.y << 16); v[3] = v[3] + __uint_as_float(ee.y & 0xffff0000u);
+        }
+        uint2 w;
+        w.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        w.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        *(uint2*)o = w;
+      }
+    }
+  }
+}
+
 static int fill(FeatPyr& d, const mxdet_feat_pyramid_t* f, int N, const char* who) {
   MXDET_REQUIRE(f != nullptr, MXDET_EINVAL, "%s: null pyramid", who);
   MXDET_REQUIRE(f->num_levels > 0 && f->num_levels <= 8, MXDET_ESHAPE, "%s: bad level count", who);
@@ -487,10 +781,11 @@ extern "C" size_t mxdet_roi_align_bwd_gather_workspace_bytes(const mxdet_feat_py
   return roi_gather_carve(d, R, &rr, &a, &b, &c, &e);
 }
 
-extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
-                                          const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
-                                          int32_t sampling_ratio, const uint16_t* grad_out, int32_t accumulate,
-                                          void* workspace, size_t workspace_bytes, mxdet_stream_t stream) {
+// mode: 0 = records + gather, 1 = records only (prepare), 2 = gather only (records already in the workspace)
+static int roi_bwd_gather_impl(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
+                               const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
+                               int32_t sampling_ratio, const uint16_t* grad_out, int32_t accumulate,
+                               void* workspace, size_t workspace_bytes, mxdet_stream_t stream, int mode) {
   clear_error();
   FeatPyr d;
   int rc = fill(d, f, N, "roi_align_bwd_gather");
@@ -501,12 +796,46 @@ extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t
   MXDET_REQUIRE(R <= 65535, MXDET_ESHAPE, "roi_align_bwd_gather: at most 65535 rois");
   for (int l = 0; l < d.num_levels; ++l)
     MXDET_REQUIRE(d.H[l] < 32768 && d.W[l] < 32768, MXDET_ESHAPE, "roi_align_bwd_gather: level %d too large", l);
-  MXDET_REQUIRE(rois && levels && grad_out, MXDET_EINVAL, "roi_align_bwd_gather: null pointer");
+  MXDET_REQUIRE(rois && levels && (grad_out || mode == 1), MXDET_EINVAL, "roi_align_bwd_gather: null pointer");
+  hipStream_t s = as_stream(stream);
   RoiRows rr; size_t o_tab, o_list, o_cnt, o_box;
   const size_t need = roi_gather_carve(d, R > 0 ? R : 1, &rr, &o_tab, &o_list, &o_cnt, &o_box);
   MXDET_REQUIRE(workspace && workspace_bytes >= need, MXDET_EWORKSPACE, "roi_align_bwd_gather: workspace %zu < %zu",
                 workspace_bytes, need);
-  hipStream_t s = as_stream(stream);
+  if (PW <= 14 && R > 0 && tuning(MXDET_TUNE_ROI_TABLE) == 0) {
+    // segment form: per-roi records, then the gather
+    static_assert(sizeof(RoiSeg) == sizeof(RoiBox), "the records live in the table form's box array");
+    RoiSeg* seg = (RoiSeg*)((char*)workspace + o_box);
+    RoiSegGrid gr;
+    memset(&gr, 0, sizeof(gr));
+    int blocks = 0;
+    const int rows_big = (int)tuning(MXDET_TUNE_ROI_ROWS);
+    for (int l = 0; l < d.num_levels; ++l) {
+      const int segs = ceil_div(d.W[l], kSegW);
+      gr.chunks[l] = ceil_div(segs, kSegWaves);
+      gr.segs_per_wg[l] = ceil_div(segs, gr.chunks[l]);
+      // finer maps get multi-row tiles (the roi list is built once per tile); coarse maps -- few pixels, many rois per
+      // pixel -- keep one row per tile for parallelism; more rois than one list round: one row (sums stay in registers)
+      gr.rows_per_wg[l] = (R > kSegChunk || d.H[l] < 64 || rows_big < 1) ? 1 : rows_big;
+      gr.bands[l] = ceil_div(d.H[l], gr.rows_per_wg[l]);
+      gr.block0[l] = blocks;
+      blocks += d.N * gr.bands[l] * gr.chunks[l];
+    }
+    gr.block0[d.num_levels] = blocks;
+    if (mode != 2)
+      hipLaunchKernelGGL(roi_bwd_box_kernel, dim3((unsigned)ceil_div((int)R, 256)), dim3(256), 0, s, d, rois, levels, (int)R,
+                         PH, PW, sampling_ratio, seg);
+    if (mode == 1) return check_launch("roi_align_bwd_gather_prepare");
+    const dim3 grid((unsigned)blocks, (unsigned)ceil_div(C, 256));
+#define MXDET_ROI_SEG(PWT, SR)                                                                                          \
+  hipLaunchKernelGGL((roi_bwd_seg_kernel<PWT, SR>), grid, dim3(kSegWaves * 64), 0, s, d, gr, C, (const RoiSeg*)seg, (int)R, \
+                     PH, PW, sampling_ratio, grad_out, accumulate)
+    if (PW <= 7) { if (sampling_ratio == 2) MXDET_ROI_SEG(7, 2); else MXDET_ROI_SEG(7, 0); }
+    else { if (sampling_ratio == 2) MXDET_ROI_SEG(14, 2); else MXDET_ROI_SEG(14, 0); }
+#undef MXDET_ROI_SEG
+    return check_launch("roi_align_bwd_gather");
+  }
+  if (mode == 1) return MXDET_OK;          // the table form builds its tables in the gather call
   RoiTab* tab = (RoiTab*)((char*)workspace + o_tab);
   unsigned short* list = (unsigned short*)((char*)workspace + o_list);
   int* cnt = (int*)((char*)workspace + o_cnt);
@@ -520,4 +849,28 @@ extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t
                      (const RoiTab*)tab, (const RoiBox*)box, (int)R, (const unsigned short*)list, (const int*)cnt, PH, PW,
                      sampling_ratio, grad_out, accumulate);
   return check_launch("roi_align_bwd_gather");
+}
+
+extern "C" int mxdet_roi_align_bwd_gather(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
+                                          const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
+                                          int32_t sampling_ratio, const uint16_t* grad_out, int32_t accumulate,
+                                          void* workspace, size_t workspace_bytes, mxdet_stream_t stream) {
+  return roi_bwd_gather_impl(f, N, C, rois, levels, R, PH, PW, sampling_ratio, grad_out, accumulate, workspace,
+                             workspace_bytes, stream, 0);
+}
+
+extern "C" int mxdet_roi_align_bwd_gather_prepare(const mxdet_feat_pyramid_t* f, int32_t N, const float* rois,
+                                                  const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
+                                                  int32_t sampling_ratio, void* workspace, size_t workspace_bytes,
+                                                  mxdet_stream_t stream) {
+  return roi_bwd_gather_impl(f, N, 4, rois, levels, R, PH, PW, sampling_ratio, nullptr, 0, workspace, workspace_bytes,
+                             stream, 1);
+}
+
+extern "C" int mxdet_roi_align_bwd_gather_prepared(const mxdet_feat_pyramid_t* f, int32_t N, int32_t C, const float* rois,
+                                                   const int32_t* levels, int64_t R, int32_t PH, int32_t PW,
+                                                   int32_t sampling_ratio, const uint16_t* grad_out, int32_t accumulate,
+                                                   void* workspace, size_t workspace_bytes, mxdet_stream_t stream) {
+  return roi_bwd_gather_impl(f, N, C, rois, levels, R, PH, PW, sampling_ratio, grad_out, accumulate, workspace,
+                             workspace_bytes, stream, 2);
 }

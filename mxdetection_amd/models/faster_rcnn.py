@@ -114,14 +114,14 @@ class FasterRCNN(DetectorBase):
             self.rpn_head.backward(self.dP, [False] * 5, flush=not defer_rpn)
         rois, _, _, num_rois = self.rpn_head.get_proposals(im_info)
         rois_s = self.bbox_head.sample(rois, num_rois, gt_boxes, step, image_offset, step_dev)
-        pooled = self.roi_extractor.forward(P, rois_s)
+        pooled = self.roi_extractor.forward(P, rois_s, prepare_gather=self.roi_bwd_gather)
         self.bbox_head.forward(pooled)
         rcnn_loss = self.bbox_head.loss_and_grad()
         mask_loss = None
         if self.with_mask:
             mrois = self.mask_head.select_rois(self.bbox_head)
             self.mask_head.targets(gt_masks)
-            mpooled = self.mask_roi_extractor.forward(P, mrois)
+            mpooled = self.mask_roi_extractor.forward(P, mrois, prepare_gather=self.roi_bwd_gather)
             self.mask_head.forward(mpooled)
             mask_loss = self.mask_head.loss_and_grad()
         # ---- backward ----

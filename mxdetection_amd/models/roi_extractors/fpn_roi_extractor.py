@@ -5,7 +5,8 @@ Plugin slot: models/roi_extractors (/root/reference/README.md:32); MXNet role co
 import torch
 
 from ...ops import dense
-from ...ops.roi_align import fpn_level_map, roi_align_backward, roi_align_backward_gather, roi_align_forward
+from ...ops.roi_align import (fpn_level_map, roi_align_backward, roi_align_backward_gather,
+                              roi_align_backward_gather_prepare, roi_align_backward_gather_workspace, roi_align_forward)
 
 
 class FPNRoIExtractor:
@@ -17,8 +18,12 @@ class FPNRoIExtractor:
         self.out = None
         self.outs = {}
         self.dacc = None
+        # forward(prepare_gather=True), i.e. training with the gather-form backward: the per-roi records of the gather are
+        # written right there, in the forward pass (they depend only on the rois), into a workspace of this extractor's own
+        self.gather_ws = {}
+        self.prepared = None
 
-    def forward(self, feats, rois):
+    def forward(self, feats, rois, prepare_gather=False):
         """feats: P2..P5 (bf16 [N,H,W,C]); rois [R,5] f32."""
         self.feats, self.rois = feats[:len(self.scales)], rois
         self.levels = fpn_level_map(rois, self.lvl_min, self.lvl_max)
@@ -28,6 +33,14 @@ class FPNRoIExtractor:
         if self.out is None:
             self.out = torch.empty((R, self.pooled[0], self.pooled[1], C), dtype=torch.bfloat16, device=self.device)
             self.outs[(R, C)] = self.out
+        self.prepared = None
+        if prepare_gather:
+            ws = self.gather_ws.get(R)
+            if ws is None:
+                ws = self.gather_ws[R] = roi_align_backward_gather_workspace(self.feats, self.scales, R, self.lvl_min)
+            roi_align_backward_gather_prepare(self.feats, self.scales, rois, self.levels, self.pooled, self.sr,
+                                              self.lvl_min, ws)
+            self.prepared = ws
         return roi_align_forward(self.feats, self.scales, rois, self.levels, self.pooled, self.sr, self.lvl_min, self.out)
 
     def backward(self, grad_out, dP, shared_acc=None, zero=True, finalize=True):
@@ -59,7 +72,7 @@ class FPNRoIExtractor:
         """Deterministic gather form: adds this extractor's gradient straight into the bf16 maps dP[l] (no fp32
         accumulators, no atomics, no zero-fill / finalize passes)."""
         roi_align_backward_gather(dP, self.scales, self.rois, self.levels, grad_out, self.sr, self.lvl_min,
-                                  accumulate=accumulate)
+                                  accumulate=accumulate, workspace=self.prepared, prepared=self.prepared is not None)
 
     def finalize(self, dP, accumulate=False):
         """dP[l] (+)= accumulators, rounded once to bf16 (one launch when both sides are views of flat buffers laid out

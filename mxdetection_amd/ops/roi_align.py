@@ -51,20 +51,45 @@ def roi_align_backward(dfeats, scales, rois, levels, grad_out, sampling_ratio=2,
 _gather_ws = {}
 
 
+def _gather_workspace(lib, d, N, R, device, workspace):
+    need = lib.mxdet_roi_align_bwd_gather_workspace_bytes(C.byref(d), N, R)
+    if workspace is None:
+        key = (device, need)
+        workspace = _gather_ws.get(key)
+        if workspace is None:
+            workspace = torch.empty((max(need, 256),), dtype=torch.uint8, device=device)
+            _gather_ws[key] = workspace
+    return workspace
+
+
+def roi_align_backward_gather_workspace(dmaps, scales, R, lvl_min=2):
+    """A workspace of the caller's own (needed when the records are prepared ahead of the gather)."""
+    lib = _lib.load()
+    d = _pyr(dmaps, scales, lvl_min)
+    need = lib.mxdet_roi_align_bwd_gather_workspace_bytes(C.byref(d), dmaps[0].shape[0], R)
+    return torch.empty((max(need, 256),), dtype=torch.uint8, device=dmaps[0].device)
+
+
+def roi_align_backward_gather_prepare(dmaps, scales, rois, levels, pooled, sampling_ratio, lvl_min, workspace):
+    """Per-roi records of the gather (they depend only on the rois): issue as soon as the rois exist."""
+    lib = _lib.load()
+    d = _pyr(dmaps, scales, lvl_min)
+    check(lib.mxdet_roi_align_bwd_gather_prepare(C.byref(d), dmaps[0].shape[0], ptr(rois), ptr(levels), rois.shape[0],
+                                                 pooled[0], pooled[1], sampling_ratio, ptr(workspace), workspace.numel(),
+                                                 stream_ptr()), "roi_align_bwd_gather_prepare")
+
+
 def roi_align_backward_gather(dmaps, scales, rois, levels, grad_out, sampling_ratio=2, lvl_min=2, accumulate=False,
-                              workspace=None):
-    """Deterministic gather form: writes (or adds to) the bf16 gradient maps dmaps[l] ([N,H,W,C]) directly."""
+                              workspace=None, prepared=False):
+    """Deterministic gather form: writes (or adds to) the bf16 gradient maps dmaps[l] ([N,H,W,C]) directly.
+    prepared: the records are already in `workspace` (roi_align_backward_gather_prepare)."""
     lib = _lib.load()
     N, C_ = dmaps[0].shape[0], dmaps[0].shape[3]
     R, PH, PW = grad_out.shape[0], grad_out.shape[1], grad_out.shape[2]
     d = _pyr(dmaps, scales, lvl_min)
-    need = lib.mxdet_roi_align_bwd_gather_workspace_bytes(C.byref(d), N, R)
-    if workspace is None:
-        key = (dmaps[0].device, need)
-        workspace = _gather_ws.get(key)
-        if workspace is None:
-            workspace = torch.empty((max(need, 256),), dtype=torch.uint8, device=dmaps[0].device)
-            _gather_ws[key] = workspace
-    check(lib.mxdet_roi_align_bwd_gather(C.byref(d), N, C_, ptr(rois), ptr(levels), R, PH, PW, sampling_ratio,
-                                         ptr(grad_out), int(accumulate), ptr(workspace), workspace.numel(), stream_ptr()),
+    assert workspace is not None or not prepared
+    workspace = _gather_workspace(lib, d, N, R, dmaps[0].device, workspace)
+    fn = lib.mxdet_roi_align_bwd_gather_prepared if prepared else lib.mxdet_roi_align_bwd_gather
+    check(fn(C.byref(d), N, C_, ptr(rois), ptr(levels), R, PH, PW, sampling_ratio,
+             ptr(grad_out), int(accumulate), ptr(workspace), workspace.numel(), stream_ptr()),
           "roi_align_bwd_gather")
