@@ -40,7 +40,8 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_WG_NS 11       /* grouped wgrad (128x128 tiles): LDS-DMA ring depth 2, 3 or 4 */
 #define MXDET_TUNE_ROI_TABLE 12   /* RoIAlign backward (gather): 1 = the three-kernel table form instead of the segment form */
 #define MXDET_TUNE_ROI_ROWS 13    /* RoIAlign backward, segment form: rows per tile on maps with >= 64 rows (default 2) */
-#define MXDET_TUNE_COUNT 14
+#define MXDET_TUNE_STATIC_TAPS 14 /* conv: 1 = stride-1 1x1 / 3x3 layers use the unrolled static-tap K loop (default 1) */
+#define MXDET_TUNE_COUNT 15
 int mxdet_debug_set_tuning(int32_t which, int64_t value);
 
 #ifdef __cplusplus

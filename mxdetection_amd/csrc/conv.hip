@@ -70,7 +70,16 @@ __device__ unsigned long long g_conv_stamp[2][8];
 // One counted s_waitcnt vmcnt + one raw s_barrier per K-step; the LDS image is lane-linear, so the
 // conflict-avoiding XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read side.
 // EXT_LDS: the caller (fused backward kernel) owns one LDS pool that this tile and the weight-gradient tile overlay.
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, bool EXT_LDS = false>
+// KU = K-steps per barrier (1 or 2). KU = 2: a ring of NS >= 4 stages consumed two at a time -- one barrier, one exposed
+// LDS-read latency and one counted wait per 128 reduction elements instead of per 64; the second step's fragments are
+// read underneath the first step's MFMAs (both stages have landed at the barrier). For the small tiles, whose steps are
+// bound by that per-step chain (barrier -> fragment reads -> 8 MFMAs) at two waves per SIMD, not by MFMA or load rate.
+// TAPS = KH*KW when the caller guarantees a stride-1 layer with that many filter taps (1 or 9; 0 = any geometry, all
+// bookkeeping at run time). With TAPS known the K loop is unrolled over the taps: the tap of every stage is a constant, its
+// displacement and filter column are loop-invariant scalars, and the ~50 dependent scalar instructions per step that
+// walked (kh, kw, channel slice) at run time disappear -- on the 64-row tiles, at 1-3 waves per SIMD, that serial
+// bookkeeping cost as many cycles per step as the step's eight MFMAs.
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, bool EXT_LDS = false, int KU = 1, int TAPS = 0>
 __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg,
                                                 unsigned char* lds_pool = nullptr) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -86,6 +95,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "rows must split evenly over the waves");
   static_assert(MT % 2 == 0, "epilogue stages two m-tiles at a time");
   static_assert(HP || (NS >= 2 && (NS - 2) * (GA + GB) <= 63), "vmcnt is a 6-bit counter");
+  static_assert(KU == 1 || (KU == 2 && !HP && NS >= 4), "two steps per barrier need a ring of at least four stages");
+  static_assert(TAPS == 0 || ((TAPS == 1 || TAPS == 9) && !PAR && !HP && KU == 1), "static taps: plain ring, 1x1 or 3x3");
   constexpr int EP_STRIDE = WTN + 4;
   constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
   constexpr int MAIN_BYTES = NBUF * STAGE * 2;
@@ -232,6 +243,23 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     wrow[i] = n * Ktot + ((lslot ^ ((rb >> 1) & SWZ)) << 3);
   }
 
+  // one stage at an explicit position (static-tap path: kh, kw are constants after unrolling)
+  auto issue_at = [&](int buf, int kh, int kw, int c0, bool live) {
+    unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
+    const int tap = live ? kh * p.KW + kw : 31;
+    const int delta = DGRAD ? c0 - (kh * p.Ws + kw) * p.C : c0 + (kh * p.Ws + kw) * p.C;     // stride 1
+    const int koff = live ? (kh * p.KW + kw) * p.C + c0 : 0;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const unsigned vo = ((a_mask[i] >> tap) & 1u) ? 2u * (unsigned)(a_off[i] + delta) : kDmaOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const unsigned wo = 2u * (unsigned)(wrow[i] + koff);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16, (int)wo, 0, 0, 0);
+    }
+  };
   // running (channel-slice, tap) position of the NEXT stage to load: uniform scalars, no divisions
   int ld_kt = 0, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
   auto issue_stage = [&](int buf) {
@@ -410,6 +438,169 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(0);
     }
+  } else if constexpr (TAPS > 0) {
+  // ---- static taps: stride-1 1x1 / 3x3, everything per step that can be a constant is one --------------------------
+  constexpr int TKW = TAPS == 9 ? 3 : 1;
+  constexpr int SL = (NS % TAPS == 0 || TAPS % NS == 0) ? (TAPS % NS == 0 ? 1 : NS) : NS;   // slices per unrolled block
+  static_assert((SL * TAPS) % NS == 0, "the ring position must repeat with the unrolled block");
+  // The uniform part of a piece's address (tap displacement + channel slice) rides in the instruction's scalar offset,
+  // which the range check ignores; the per-lane part must then be non-negative on its own, so the descriptor starts
+  // `bias` elements before the tensor (padding rows / columns of the first image give negative tap-(0,0) offsets).
+  // Data gradient: offsets are taken from the LAST tap's source pixel so that every displacement is >= 0.
+  const int bias_el = (p.pad * p.Ws + p.pad) * p.C;
+  const int rebase = DGRAD ? ((p.KH - 1) * p.Ws + (p.KW - 1)) * p.C : 0;
+  const __amdgpu_buffer_rsrc_t rsrc_xs =
+      make_rsrc(p.x - bias_el, 2u * (unsigned)(p.N * p.Hs * p.Ws) * (unsigned)p.C + 2u * (unsigned)bias_el);
+  unsigned voa[GA], vow[GB];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    voa[i] = 2u * (unsigned)(a_off[i] - rebase + bias_el);
+    if (TAPS == 1) voa[i] = (a_mask[i] & 1u) ? voa[i] : kDmaOob;
+  }
+#pragma unroll
+  for (int i = 0; i < GB; ++i) vow[i] = 2u * (unsigned)wrow[i];
+  const unsigned lds_w0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  auto issue_static = [&](int buf, int tap, int c0, bool live) {      // buf, tap: constants after unrolling
+    const int kh = tap / TKW, kw = tap % TKW;
+    const int disp = DGRAD ? ((p.KH - 1 - kh) * p.Ws + (p.KW - 1 - kw)) * p.C : (kh * p.Ws + kw) * p.C;
+    const int so_a = live ? 2 * (disp + c0) : 0;                       // dummy stages past the end: see below
+    const int so_b = live ? 2 * (tap * p.C + c0) : 0;
+    unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      unsigned vo = voa[i];
+      if (TAPS != 1) vo = ((a_mask[i] >> tap) & 1u) ? vo : kDmaOob;
+      // a dummy stage has no displacement: its tap-(0,0) address may lie in front of the tensor -- it loads nothing
+      if (!live) vo = kDmaOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xs, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, so_a, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16, (int)vow[i], so_b, 0, 0);
+  };
+  (void)lds_w0;
+  // fragment addresses: two per operand (the two 32-deep halves differ in the swizzled chunk), rows i / j at +2 KiB each
+  const uint16_t* fa0 = smem + lds_off(wm * WTM + frow, fq);
+  const uint16_t* fa1 = smem + lds_off(wm * WTM + frow, 4 + fq);
+  const uint16_t* fb0 = smem + BM * 64 + lds_off(wn * WTN + frow, fq);
+  const uint16_t* fb1 = smem + BM * 64 + lds_off(wn * WTN + frow, 4 + fq);
+  const int nslices = p.C >> 6;
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue_static(s0, s0 % TAPS, (s0 / TAPS) * 64, s0 < KT);
+  for (int cs = 0; cs < nslices; cs += SL) {
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      if (SL > 1 && cs + sl >= nslices) break;                        // wave-uniform
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int step = sl * TAPS + tp;                              // constants after unrolling
+        const int cur = step % NS, nxt = (step + NS - 1) % NS;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (GA + GB)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // all fragment reads of the step first (immediate offsets), then the next stage's loads, then the MFMAs behind
+        // counted lgkmcnt waits: one exposed LDS latency per step, underneath the DMA issue
+        bf16x8_t af0[MT], bf0[NT], af1[MT], bf1[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af0[i] = *(const bf16x8_t*)(fa0 + cur * STAGE + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf0[j] = *(const bf16x8_t*)(fb0 + cur * STAGE + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af1[i] = *(const bf16x8_t*)(fa1 + cur * STAGE + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf1[j] = *(const bf16x8_t*)(fb1 + cur * STAGE + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int ahead = tp + NS - 1;
+          const int atap = ahead % TAPS, aslice = ahead / TAPS;
+          issue_static(nxt, atap, (cs + sl + aslice) * 64, cs + sl + aslice < nslices);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  } else if constexpr (KU == 2) {
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 2; ++s0) issue_stage(s0);
+  int cur = 0, nxt = NS - 2;
+  const int KT2 = (KT + 1) >> 1;           // an odd tail multiplies one all-zero stage (its loads were out of range)
+  for (int it = 0; it < KT2; ++it) {
+    // both stages of this iteration have landed once all but the (NS-4) youngest stages' loads of this wave are done
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 4) * (GA + GB)) : "memory");
+    __builtin_amdgcn_s_barrier();          // ... in every wave; and every wave is done with the two buffers refilled next
+    asm volatile("" ::: "memory");
+    const int cur1 = (cur + 1 == NS) ? 0 : cur + 1;
+    const uint16_t* sa0 = smem + cur * STAGE;
+    const uint16_t* sb0 = sa0 + BM * 64;
+    const uint16_t* sa1 = smem + cur1 * STAGE;
+    const uint16_t* sb1 = sa1 + BM * 64;
+    bf16x8_t a00[MT], b00[NT], a01[MT], b01[NT], a10[MT], b10[NT], a11[MT], b11[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a00[i] = *(const bf16x8_t*)(sa0 + lds_off(wm * WTM + i * 16 + frow, fq));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b00[j] = *(const bf16x8_t*)(sb0 + lds_off(wn * WTN + j * 16 + frow, fq));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a01[i] = *(const bf16x8_t*)(sa0 + lds_off(wm * WTM + i * 16 + frow, 4 + fq));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b01[j] = *(const bf16x8_t*)(sb0 + lds_off(wn * WTN + j * 16 + frow, 4 + fq));
+    __builtin_amdgcn_sched_barrier(0);
+    issue_stage(nxt);
+    issue_stage((nxt + 1 == NS) ? 0 : nxt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a10[i] = *(const bf16x8_t*)(sa1 + lds_off(wm * WTM + i * 16 + frow, fq));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b10[j] = *(const bf16x8_t*)(sb1 + lds_off(wn * WTN + j * 16 + frow, fq));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a11[i] = *(const bf16x8_t*)(sa1 + lds_off(wm * WTM + i * 16 + frow, 4 + fq));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b11[j] = *(const bf16x8_t*)(sb1 + lds_off(wn * WTN + j * 16 + frow, 4 + fq));
+    __builtin_amdgcn_s_setprio(1);
+#ifndef MXDET_ABL_NOMFMA
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00[i], b00[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01[i], b01[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10[i], b10[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11[i], b11[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { asm volatile("" ::"v"(a00[i]), "v"(a01[i]), "v"(a10[i]), "v"(a11[i])); }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { asm volatile("" ::"v"(b00[j]), "v"(b01[j]), "v"(b10[j]), "v"(b11[j])); }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    cur = (cur1 + 1 == NS) ? 0 : cur1 + 1;
+    nxt = (nxt + 2 >= NS) ? nxt + 2 - NS : nxt + 2;
+  }
   } else {
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) issue_stage(s0);
@@ -587,10 +778,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
-  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR, false, KU, TAPS>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped form: independent convolutions that share one tile configuration (the 3x3 of every pyramid level of an RPN
@@ -602,7 +793,7 @@ struct ConvG {
   int block0, nblocks;
 };
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, int TAPS = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
   int lo = 0, hi = n - 1;
@@ -615,7 +806,7 @@ conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
   const int nb = table[lo].nblocks;
   if (b >= nb) return;                      // alignment padding between items
   const ConvP p = table[lo].p;
-  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false>(p, b, nb);
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false, false, 1, TAPS>(p, b, nb);
 }
 
 // Fused backward launch: the data-gradient tiles of a layer (grouped-table form, blocks [0, cgrid)) and a slice of the
@@ -668,7 +859,7 @@ static int thr_t64() { return (int)tuning(MXDET_TUNE_T64); }
 static int thr_t128() { return (int)tuning(MXDET_TUNE_T128); }
 static int thr_par64() { return (int)tuning(MXDET_TUNE_PAR64); }
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0>
 static int launch_cfg(ConvP& p, hipStream_t s) {
   if (PAR) {   // rows grouped by parity class: tiles never straddle two classes
     int t = 0;
@@ -682,7 +873,7 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
   if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);   // caller may restrict the row range
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR>), dim3((unsigned)nwg), dim3(64 * WM * WN),
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, KU, TAPS>), dim3((unsigned)nwg), dim3(64 * WM * WN),
                      0, s, p);
   return check_launch("conv2d");
 }
@@ -716,6 +907,19 @@ static int launch(ConvP& p, hipStream_t s) {
     case 18: return launch_cfg<64, 64, 2, 2, 5, DGRAD>(p, s);     // 80 KiB: deep ring for grids of <= 2 workgroups per CU
     case 19: return launch_cfg<64, 64, 2, 2, 4, DGRAD>(p, s);     // 64 KiB
     case 26: return launch_cfg<64, 128, 2, 2, 5, DGRAD>(p, s);    // 120 KiB: one workgroup per CU, four stages in flight
+    // two K-steps per barrier (KU = 2)
+    case 30: return launch_cfg<64, 64, 2, 2, 4, DGRAD, false, 2>(p, s);    // 64 KiB
+    case 31: return launch_cfg<64, 128, 2, 2, 4, DGRAD, false, 2>(p, s);   // 96 KiB
+    case 32: return launch_cfg<64, 64, 2, 2, 6, DGRAD, false, 2>(p, s);    // 96 KiB, four stages in flight
+    case 33: return launch_cfg<128, 64, 4, 1, 4, DGRAD, false, 2>(p, s);   // 96 KiB
+    case 34: return launch_cfg<128, 128, 2, 2, 4, DGRAD, false, 2>(p, s);  // 128 KiB
+    // static taps (the caller of these test cases passes a matching stride-1 layer)
+    case 40: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 3, DGRAD, false, 1, 9>(p, s);
+    case 42: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 4, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 4, DGRAD, false, 1, 9>(p, s);
+    case 43: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 9>(p, s);
+    case 44: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 9>(p, s);
+    case 45: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
+    case 41: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
     // half-stage pipeline (NS = 1) variants
     case 20: return launch_cfg<64, 64, 2, 2, 1, DGRAD>(p, s);
     case 21: return launch_cfg<64, 128, 2, 2, 1, DGRAD>(p, s);
@@ -725,6 +929,13 @@ static int launch(ConvP& p, hipStream_t s) {
     case 25: return launch_cfg<256, 128, 4, 2, 1, DGRAD>(p, s);
     default: break;
   }
+  // stride-1 1x1 / 3x3 layers (all but the four stride-2 convolutions and the stem): the unrolled static-tap K loop
+  const int taps = p.KH * p.KW;
+  const int st = (p.stride != 1 || tuning(MXDET_TUNE_STATIC_TAPS) == 0) ? 0 : (taps == 1 && p.pad == 0) ? 1 : (p.KH == 3 && p.KW == 3 && p.pad == 1) ? 9 : 0;
+#define MXDET_LAUNCH_ST(BM, BN, WM, WN, NS)                                                        \
+  (st == 1 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1, 1>(p, s)                              \
+           : st == 9 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1, 9>(p, s)                    \
+                     : launch_cfg<BM, BN, WM, WN, NS, DGRAD>(p, s))
   if constexpr (DGRAD) {
     if (p.stride == 2 && force == 0) {
       // stride-2 data gradient: parity-grouped rows, only the taps that exist (a quarter of the MACs)
@@ -740,7 +951,7 @@ static int launch(ConvP& p, hipStream_t s) {
       return launch_cfg<64, 64, 2, 2, 3, true, true>(p, s);
     }
   }
-  if (p.Ncols <= 64) return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
+  if (p.Ncols <= 64) return MXDET_LAUNCH_ST(128, 64, 4, 1, 2);
   if (t128 >= thr_t128() && K > 256) {
     // Largest layers: 256x256 tiles (one 8-wave workgroup per CU, half the LDS-DMA pieces per MFMA of the 128x128
     // tile) for as many whole rounds of the chip's 256 CUs as the layer has; the remaining rows -- a partial round
@@ -759,13 +970,14 @@ static int launch(ConvP& p, hipStream_t s) {
     // the remaining rows (a partial round of 256x256 tiles would idle most CUs for a whole tile time): small tiles,
     // so that every CU gets a share of the tail (measured: 64x64 tiles 208 workgroups, vs 128x128 tiles 52 workgroups)
     switch ((int)tuning(MXDET_TUNE_TAIL)) {
-      case 1: return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
-      case 2: return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
-      default: return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
+      case 1: return MXDET_LAUNCH_ST(64, 128, 2, 2, 2);
+      case 2: return MXDET_LAUNCH_ST(64, 64, 2, 2, 3);
+      default: return MXDET_LAUNCH_ST(128, 128, 2, 2, 2);
     }
   }
-  if (t64 >= thr_t64()) return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
-  return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
+  if (t64 >= thr_t64()) return MXDET_LAUNCH_ST(64, 128, 2, 2, 2);
+  return MXDET_LAUNCH_ST(64, 64, 2, 2, 3);
+#undef MXDET_LAUNCH_ST
 }
 
 static int validate(const mxdet_conv_desc_t* d, const char* who) {
@@ -843,9 +1055,17 @@ extern "C" int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy
 
 // ---- grouped convolutions -------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD>
-static void launch_grouped_cfg(const ConvG* table, int n, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((conv_igemm_grouped_kernel<BM, BN, WM, WN, NS, DGRAD>), dim3((unsigned)grid), dim3(64 * WM * WN),
-                     0, s, table, n);
+static void launch_grouped_cfg(const ConvG* table, int n, int grid, hipStream_t s, int tapclass) {
+  // tapclass: 0 = any geometry, 1 = every item a stride-1 1x1, 2 = every item a stride-1 3x3 (static-tap K loop)
+  if (tapclass == 1)
+    hipLaunchKernelGGL((conv_igemm_grouped_kernel<BM, BN, WM, WN, NS, DGRAD, 1>), dim3((unsigned)grid), dim3(64 * WM * WN),
+                       0, s, table, n);
+  else if (tapclass == 2)
+    hipLaunchKernelGGL((conv_igemm_grouped_kernel<BM, BN, WM, WN, NS, DGRAD, 9>), dim3((unsigned)grid), dim3(64 * WM * WN),
+                       0, s, table, n);
+  else
+    hipLaunchKernelGGL((conv_igemm_grouped_kernel<BM, BN, WM, WN, NS, DGRAD>), dim3((unsigned)grid), dim3(64 * WM * WN),
+                       0, s, table, n);
 }
 
 static const int kGroupedTiles[4][2] = {{128, 64}, {128, 128}, {64, 128}, {64, 64}};   // cfg -> BM, BN
@@ -861,6 +1081,7 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
   ConvG* t = (ConvG*)table_host;
   long long t64 = 0, t128_max = 0;
   int max_cols = 0, kmax = 0;
+  int tapclass = -1;          // -1: not decided, 0: mixed / strided
   for (int i = 0; i < n; ++i) {
     const mxdet_conv_desc_t* d = &items[i].desc;
     int rc = validate(d, "conv2d_grouped_plan");
@@ -890,6 +1111,10 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
       p.M = d->N * d->H * d->W;
     }
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    {
+      const int tc = d->stride != 1 ? 0 : (d->KH == 1 && d->KW == 1 && d->pad == 0) ? 1 : (d->KH == 3 && d->KW == 3 && d->pad == 1) ? 2 : 0;
+      tapclass = tapclass < 0 ? tc : (tapclass == tc ? tc : 0);
+    }
     t64 += (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 128);
     long long t128 = (long long)ceil_div(p.M, 128) * ceil_div(p.Ncols, 128);
     t128_max = t128 > t128_max ? t128 : t128_max;
@@ -913,7 +1138,8 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
     blocks += (long long)align_up((size_t)t[i].nblocks, 8);
     MXDET_REQUIRE(blocks < (1ll << 30), MXDET_ESHAPE, "conv2d_grouped_plan: group too large");
   }
-  *cfg_out = cfg;
+  if (tuning(MXDET_TUNE_STATIC_TAPS) == 0 || tapclass < 0) tapclass = 0;
+  *cfg_out = cfg + 4 * tapclass;          // tile configuration + 4 x tap class
   *grid_out = (int32_t)blocks;
   return MXDET_OK;
 }
@@ -922,22 +1148,24 @@ extern "C" int mxdet_conv2d_grouped(const void* table_dev, int32_t n, int32_t ki
                                     mxdet_stream_t stream) {
   clear_error();
   MXDET_REQUIRE(table_dev && n > 0 && grid > 0, MXDET_EINVAL, "conv2d_grouped: empty group");
-  MXDET_REQUIRE((kind == 0 || kind == 1) && cfg >= 0 && cfg <= 3, MXDET_EINVAL, "conv2d_grouped: bad kind / cfg");
+  MXDET_REQUIRE((kind == 0 || kind == 1) && cfg >= 0 && cfg <= 11, MXDET_EINVAL, "conv2d_grouped: bad kind / cfg");
   const ConvG* t = (const ConvG*)table_dev;
   hipStream_t s = as_stream(stream);
+  const int tc = cfg >> 2;
+  cfg &= 3;
   if (kind == 0) {
     switch (cfg) {
-      case 0: launch_grouped_cfg<128, 64, 4, 1, 2, false>(t, n, grid, s); break;
-      case 1: launch_grouped_cfg<128, 128, 2, 2, 2, false>(t, n, grid, s); break;
-      case 2: launch_grouped_cfg<64, 128, 2, 2, 2, false>(t, n, grid, s); break;
-      default: launch_grouped_cfg<64, 64, 2, 2, 3, false>(t, n, grid, s); break;
+      case 0: launch_grouped_cfg<128, 64, 4, 1, 2, false>(t, n, grid, s, tc); break;
+      case 1: launch_grouped_cfg<128, 128, 2, 2, 2, false>(t, n, grid, s, tc); break;
+      case 2: launch_grouped_cfg<64, 128, 2, 2, 2, false>(t, n, grid, s, tc); break;
+      default: launch_grouped_cfg<64, 64, 2, 2, 3, false>(t, n, grid, s, tc); break;
     }
   } else {
     switch (cfg) {
-      case 0: launch_grouped_cfg<128, 64, 4, 1, 2, true>(t, n, grid, s); break;
-      case 1: launch_grouped_cfg<128, 128, 2, 2, 2, true>(t, n, grid, s); break;
-      case 2: launch_grouped_cfg<64, 128, 2, 2, 2, true>(t, n, grid, s); break;
-      default: launch_grouped_cfg<64, 64, 2, 2, 3, true>(t, n, grid, s); break;
+      case 0: launch_grouped_cfg<128, 64, 4, 1, 2, true>(t, n, grid, s, tc); break;
+      case 1: launch_grouped_cfg<128, 128, 2, 2, 2, true>(t, n, grid, s, tc); break;
+      case 2: launch_grouped_cfg<64, 128, 2, 2, 2, true>(t, n, grid, s, tc); break;
+      default: launch_grouped_cfg<64, 64, 2, 2, 3, true>(t, n, grid, s, tc); break;
     }
   }
   return check_launch("conv2d_grouped");

@@ -105,8 +105,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
   }
   const int ntaps = p.KH * p.KW;
   const int tap = b % ntaps; b /= ntaps;
-  const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
-  const int co_t = b % p.co_tiles; b /= p.co_tiles;
+  // the operand with more channels is the one to share inside an XCD: its tile index moves slowest, so the workgroups
+  // next to each other re-read THAT tile from L2 (the FC6 weight gradient, 98 x 8 tiles, fetched its 25.7 MB input
+  // eight times -- once per XCD -- with ci fastest)
+  int ci_t, co_t;
+  if (p.Cin > p.Cout) { co_t = b % p.co_tiles; b /= p.co_tiles; ci_t = b % p.ci_tiles; b /= p.ci_tiles; }
+  else { ci_t = b % p.ci_tiles; b /= p.ci_tiles; co_t = b % p.co_tiles; b /= p.co_tiles; }
   const int ks = b;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = co_t * 128, ci0 = ci_t * 128;

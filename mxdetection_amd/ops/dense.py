@@ -147,9 +147,9 @@ def fused_dgrad(call, device, wplan, w_begin, w_end, wbuf):
         except _lib.MxdetError:
             plan = False
         _group_plans[key] = plan
-    if plan is False or plan.cfg not in (2, 3):
+    if plan is False or (plan.cfg & 3) not in (2, 3):    # (cfg = tile configuration + 4 x tap class)
         return False
-    check(_lib.load().mxdet_fused_dgrad_wgrad(ptr(plan.table), plan.n, plan.cfg, plan.grid, ptr(wplan.table), wplan.n,
+    check(_lib.load().mxdet_fused_dgrad_wgrad(ptr(plan.table), plan.n, plan.cfg & 3, plan.grid, ptr(wplan.table), wplan.n,
                                               w_begin, w_end, ptr(wbuf), stream_ptr()), "fused_dgrad_wgrad")
     return True
 

@@ -38,7 +38,10 @@ def main():
     if len(sys.argv) > 2:
         lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_MINSTEPS"], int(sys.argv[2]))
     g = torch.Generator(device="cuda").manual_seed(1)
-    for N, H, W, Cin, Cout, K in SHAPES:
+    sel = os.environ.get("WG_SHAPES")          # e.g. "0,2": only these rows of SHAPES
+    shapes = [SHAPES[int(i)] for i in sel.split(",")] if sel else SHAPES
+    eager = os.environ.get("WG_EAGER") == "1"  # plain launches (PMC passes count per dispatch)
+    for N, H, W, Cin, Cout, K in shapes:
         pad = K // 2
         x = torch.randn((N, H, W, Cin), device="cuda", generator=g).to(torch.bfloat16)
         dy = torch.randn((N, H, W, Cout), device="cuda", generator=g).to(torch.bfloat16)
@@ -49,7 +52,13 @@ def main():
             lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], big)
             plan = dense.GroupedWgrad([(x, dy, K, K, 1, pad, dw, None, False)], "cuda")
             ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
-            t = time_graph(lambda: plan.launch(ws))
+            if eager:
+                for _ in range(3):
+                    plan.launch(ws)
+                torch.cuda.synchronize()
+                t = 1.0
+            else:
+                t = time_graph(lambda: plan.launch(ws))
             out.append("%s grid %5d slabs %6.1f MB  %7.1f us %6.1f TF" % ("big  " if big else "small", plan.grid_big or plan.grid_wgrad,
                                                                             plan.workspace_bytes / 1e6, t * 1e6, fl / t / 1e12))
         print("N=%d %dx%d %d->%d %dx%d | %s | %s" % (N, H, W, Cin, Cout, K, K, out[0], out[1]), flush=True)

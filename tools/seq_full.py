@@ -10,7 +10,7 @@ with open(sys.argv[1]) as f:
         wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", "1")) or 1)
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name[:58], r["Queue_Id"], grid // max(wg, 1)))
 rows.sort()
-st = [i for i, r in enumerate(rows) if "stem_conv" in r[2]]
+st = [i for i, r in enumerate(rows) if "stem_conv" in r[2] or "stem_pool" in r[2]]
 lo, hi = st[-3], st[-2]
 t0 = rows[lo][0]
 print("step wall %.1f us" % ((max(r[1] for r in rows[lo:hi]) - t0) / 1e3))
