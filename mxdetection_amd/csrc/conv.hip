@@ -162,6 +162,31 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const int hw_d = p.Hd * p.Wd;
   const bool smallm = p.M < (1 << 24);
   const float rcp_hw = 1.0f / (float)hw_d, rcp_w = 1.0f / (float)p.Wd;
+  const int Ktot = ntaps * p.C;
+  const int KT = PAR ? (nkh * nkw * p.C) >> 6 : Ktot >> 6;
+  int wrow[GB];          // element offset of this lane's chunk in filter row n
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    int rb = (wid * GB + i) * RPI + lrow;
+    int n = n0 + rb;
+    n = n < p.Ncols ? n : p.Ncols - 1;   // rows past Ncols read a valid row; their columns are never stored
+    wrow[i] = n * Ktot + ((lslot ^ ((rb >> 1) & SWZ)) << 3);
+  }
+  // static-tap path: the filter pieces of the prologue stages go out right here, before the per-row gather geometry
+  // (two divisions and the tap masks per row, ~2 us of a 3x3 workgroup's life) -- the weights of a layer are cold in L2
+  // at its first touch, so their latency runs underneath that arithmetic
+  auto issue_b = [&](int buf, int tap, int c0, bool live) {
+    const int so_b = live ? 2 * (tap * p.C + c0) : 0;
+    unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16,
+                                               (int)(2u * (unsigned)wrow[i]), so_b, 0, 0);
+  };
+  if constexpr (TAPS > 0) {
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) issue_b(s0, s0 % TAPS, (s0 / TAPS) * 64, s0 < KT);
+  }
   int a_off[GA];
   unsigned a_mask[GA];
 #pragma unroll
@@ -214,6 +239,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
             bool ok = th >= 0 && tw >= 0 && th == hs * p.stride && tw == ws * p.stride && hs < p.Hs && ws < p.Ws;
             if (ok) mask |= 1u << (kh * p.KW + kw);
           }
+      } else if (TAPS == 9) {
+        // 3x3, pad 1, stride 1: h0 / w0 are one off the destination pixel, the middle tap always exists
+        const unsigned rlo = (DGRAD ? h0 < p.Hs : h0 >= 0) ? 1u : 0u, rhi = (DGRAD ? h0 - 2 >= 0 : h0 + 2 < p.Hs) ? 4u : 0u;
+        const unsigned clo = (DGRAD ? w0 < p.Ws : w0 >= 0) ? 1u : 0u, chi = (DGRAD ? w0 - 2 >= 0 : w0 + 2 < p.Ws) ? 4u : 0u;
+        const unsigned rowm = rlo | 2u | rhi, colm = clo | 2u | chi;
+        mask = ((rowm & 1u) ? colm : 0u) | (colm << 3) | ((rowm & 4u) ? colm << 6 : 0u);
       } else {
         // a tap is inside the map iff its row and its column are: two small bit masks instead of KH*KW tests
         unsigned rowm = 0, colm = 0;
@@ -231,16 +262,6 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     }
     a_off[i] = off;
     a_mask[i] = mask;
-  }
-  const int Ktot = ntaps * p.C;
-  const int KT = PAR ? (nkh * nkw * p.C) >> 6 : Ktot >> 6;
-  int wrow[GB];          // element offset of this lane's chunk in filter row n
-#pragma unroll
-  for (int i = 0; i < GB; ++i) {
-    int rb = (wid * GB + i) * RPI + lrow;
-    int n = n0 + rb;
-    n = n < p.Ncols ? n : p.Ncols - 1;   // rows past Ncols read a valid row; their columns are never stored
-    wrow[i] = n * Ktot + ((lslot ^ ((rb >> 1) & SWZ)) << 3);
   }
 
   // one stage at an explicit position (static-tap path: kh, kw are constants after unrolling)
@@ -451,20 +472,16 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const int rebase = DGRAD ? ((p.KH - 1) * p.Ws + (p.KW - 1)) * p.C : 0;
   const __amdgpu_buffer_rsrc_t rsrc_xs =
       make_rsrc(p.x - bias_el, 2u * (unsigned)(p.N * p.Hs * p.Ws) * (unsigned)p.C + 2u * (unsigned)bias_el);
-  unsigned voa[GA], vow[GB];
+  unsigned voa[GA];
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
     voa[i] = 2u * (unsigned)(a_off[i] - rebase + bias_el);
     if (TAPS == 1) voa[i] = (a_mask[i] & 1u) ? voa[i] : kDmaOob;
   }
-#pragma unroll
-  for (int i = 0; i < GB; ++i) vow[i] = 2u * (unsigned)wrow[i];
-  const unsigned lds_w0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
-  auto issue_static = [&](int buf, int tap, int c0, bool live) {      // buf, tap: constants after unrolling
+  auto issue_a = [&](int buf, int tap, int c0, bool live) {           // buf, tap: constants after unrolling
     const int kh = tap / TKW, kw = tap % TKW;
     const int disp = DGRAD ? ((p.KH - 1 - kh) * p.Ws + (p.KW - 1 - kw)) * p.C : (kh * p.Ws + kw) * p.C;
     const int so_a = live ? 2 * (disp + c0) : 0;                       // dummy stages past the end: see below
-    const int so_b = live ? 2 * (tap * p.C + c0) : 0;
     unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
@@ -474,19 +491,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       if (!live) vo = kDmaOob;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xs, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, so_a, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < GB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16, (int)vow[i], so_b, 0, 0);
   };
-  (void)lds_w0;
   // fragment addresses: two per operand (the two 32-deep halves differ in the swizzled chunk), rows i / j at +2 KiB each
   const uint16_t* fa0 = smem + lds_off(wm * WTM + frow, fq);
   const uint16_t* fa1 = smem + lds_off(wm * WTM + frow, 4 + fq);
   const uint16_t* fb0 = smem + BM * 64 + lds_off(wn * WTN + frow, fq);
   const uint16_t* fb1 = smem + BM * 64 + lds_off(wn * WTN + frow, 4 + fq);
   const int nslices = p.C >> 6;
+  // (the prologue's filter pieces went out before the geometry; its gather pieces follow them, so stage 0 is complete
+  // once only the later stages' gather pieces are outstanding)
 #pragma unroll
-  for (int s0 = 0; s0 < NS - 1; ++s0) issue_static(s0, s0 % TAPS, (s0 / TAPS) * 64, s0 < KT);
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue_a(s0, s0 % TAPS, (s0 / TAPS) * 64, s0 < KT);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * GA) : "memory");
   for (int cs = 0; cs < nslices; cs += SL) {
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
@@ -513,7 +529,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         {
           const int ahead = tp + NS - 1;
           const int atap = ahead % TAPS, aslice = ahead / TAPS;
-          issue_static(nxt, atap, (cs + sl + aslice) * 64, cs + sl + aslice < nslices);
+          issue_a(nxt, atap, (cs + sl + aslice) * 64, cs + sl + aslice < nslices);
+          issue_b(nxt, atap, (cs + sl + aslice) * 64, cs + sl + aslice < nslices);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
