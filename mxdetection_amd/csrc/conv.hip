@@ -74,8 +74,8 @@ __device__ unsigned long long g_conv_stamp[2][8];
 // LDS-read latency and one counted wait per 128 reduction elements instead of per 64; the second step's fragments are
 // read underneath the first step's MFMAs (both stages have landed at the barrier). For the small tiles, whose steps are
 // bound by that per-step chain (barrier -> fragment reads -> 8 MFMAs) at two waves per SIMD, not by MFMA or load rate.
-// TAPS = KH*KW when the caller guarantees a stride-1 layer with that many filter taps (1 or 9; 0 = any geometry, all
-// bookkeeping at run time). With TAPS known the K loop is unrolled over the taps: the tap of every stage is a constant, its
+// TAPS = KH*KW when the caller guarantees a 1x1 (stride 1, pad 0) or a 3x3 (pad 1; stride 1, or any stride in the
+// forward direction) layer; 0 = any geometry, all bookkeeping at run time. With TAPS known the K loop is unrolled over the taps: the tap of every stage is a constant, its
 // displacement and filter column are loop-invariant scalars, and the ~50 dependent scalar instructions per step that
 // walked (kh, kw, channel slice) at run time disappear -- on the 64-row tiles, at 1-3 waves per SIMD, that serial
 // bookkeeping cost as many cycles per step as the step's eight MFMAs.
@@ -240,7 +240,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
             if (ok) mask |= 1u << (kh * p.KW + kw);
           }
       } else if (TAPS == 9) {
-        // 3x3, pad 1, stride 1: h0 / w0 are one off the destination pixel, the middle tap always exists
+        // 3x3, pad 1 (forward: any stride; data gradient: stride 1): the middle tap always exists
         const unsigned rlo = (DGRAD ? h0 < p.Hs : h0 >= 0) ? 1u : 0u, rhi = (DGRAD ? h0 - 2 >= 0 : h0 + 2 < p.Hs) ? 4u : 0u;
         const unsigned clo = (DGRAD ? w0 < p.Ws : w0 >= 0) ? 1u : 0u, chi = (DGRAD ? w0 - 2 >= 0 : w0 + 2 < p.Ws) ? 4u : 0u;
         const unsigned rowm = rlo | 2u | rhi, colm = clo | 2u | chi;
@@ -948,7 +948,9 @@ static int launch(ConvP& p, hipStream_t s) {
   }
   // stride-1 1x1 / 3x3 layers (all but the four stride-2 convolutions and the stem): the unrolled static-tap K loop
   const int taps = p.KH * p.KW;
-  const int st = (p.stride != 1 || tuning(MXDET_TUNE_STATIC_TAPS) == 0) ? 0 : (taps == 1 && p.pad == 0) ? 1 : (p.KH == 3 && p.KW == 3 && p.pad == 1) ? 9 : 0;
+  // (a forward 3x3 may be strided: its tap displacements do not depend on the stride; a strided data gradient may not)
+  const int st = ((p.stride != 1 && (DGRAD || taps == 1)) || tuning(MXDET_TUNE_STATIC_TAPS) == 0) ? 0
+                 : (taps == 1 && p.pad == 0) ? 1 : (p.KH == 3 && p.KW == 3 && p.pad == 1) ? 9 : 0;
 #define MXDET_LAUNCH_ST(BM, BN, WM, WN, NS)                                                        \
   (st == 1 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1, 1>(p, s)                              \
            : st == 9 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1, 9>(p, s)                    \
@@ -1129,7 +1131,8 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
     }
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
     {
-      const int tc = d->stride != 1 ? 0 : (d->KH == 1 && d->KW == 1 && d->pad == 0) ? 1 : (d->KH == 3 && d->KW == 3 && d->pad == 1) ? 2 : 0;
+      const int tc = (d->stride != 1 && (kind == 1 || d->KH * d->KW == 1)) ? 0
+                     : (d->KH == 1 && d->KW == 1 && d->pad == 0) ? 1 : (d->KH == 3 && d->KW == 3 && d->pad == 1) ? 2 : 0;
       tapclass = tapclass < 0 ? tc : (tapclass == tc ? tc : 0);
     }
     t64 += (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 128);

@@ -132,13 +132,16 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
   const int d_img = BKP / HW, d_rem = BKP - d_img * HW;
   const int d_ho = d_rem / p.Wo, d_wo = d_rem - d_ho * p.Wo;
   // (the K loop is VALU-issue bound -- four waves per SIMD share one vector issue port with their MFMAs -- so the
-  // per-step bookkeeping is kept to adds, compares and selects: the source offset advances by constants picked by the
-  // two carries instead of being recomputed with multiplies)
-  int c_ho[GI], c_wo[GI], c_m[GI], c_offy[GI], c_offx[GI];
+  // per-step bookkeeping is adds, compares and selects only: a row carries the SOURCE coordinates of this tap (hi, wi)
+  // and its source offset; all three advance by constants picked by the two carries -- no multiplies, no recomputation)
+  int c_hi[GI], c_wi[GI], c_m[GI], c_offy[GI], c_offx[GI];
   bool c_yok[GI], c_xok[GI];
   const int stepx0 = ((d_img * p.H + d_ho * p.stride) * p.W + d_wo * p.stride) * p.Cin;
   const int stepx_w = (p.stride * p.W - p.Wo * p.stride) * p.Cin;
   const int stepx_h = (p.H * p.W - p.Ho * p.stride * p.W) * p.Cin;
+  const int d_wo_s = d_wo * p.stride, d_ho_s = d_ho * p.stride;
+  const int wrap_w = p.Wo * p.stride, wrap_h = p.Ho * p.stride;
+  const int wi_lim = wrap_w - p.pad + kw, hi_lim = wrap_h - p.pad + kh;    // first coordinate of the NEXT row / image
 #pragma unroll
   for (int i = 0; i < GI; ++i) {
     int row = (wid * GI + i) * 4 + lrow;
@@ -148,11 +151,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
     c_m[i] = m;
     const int img = m / HW;
     int rem = m - img * HW;
-    c_ho[i] = rem / p.Wo;
-    c_wo[i] = rem - c_ho[i] * p.Wo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    c_hi[i] = ho * p.stride - p.pad + kh;
+    c_wi[i] = wo * p.stride - p.pad + kw;
     c_offy[i] = m * p.Cout + co0 + chunk;
     // element offset of the tap's source pixel (may lie outside the map: then the lane reads nothing)
-    c_offx[i] = ((img * p.H + c_ho[i] * p.stride - p.pad + kh) * p.W + c_wo[i] * p.stride - p.pad + kw) * p.Cin + ci0 + chunk;
+    c_offx[i] = ((img * p.H + c_hi[i]) * p.W + c_wi[i]) * p.Cin + ci0 + chunk;
     c_yok[i] = (co0 + chunk) < p.Cout;
     c_xok[i] = (ci0 + chunk) < p.Cin;
   }
@@ -161,9 +165,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
 #pragma unroll
     for (int i = 0; i < GI; ++i) {
       const bool mok = live && c_m[i] < p.M;
-      const int hi = c_ho[i] * p.stride - p.pad + kh, wi = c_wo[i] * p.stride - p.pad + kw;
       const bool yok = mok && c_yok[i];
-      const bool xok = mok && c_xok[i] && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+      const bool xok = mok && c_xok[i] && ((unsigned)c_hi[i] < (unsigned)p.H) && ((unsigned)c_wi[i] < (unsigned)p.W);
       const int offx = c_offx[i];
 #ifdef MXDET_WG_L2TEST   /* diagnostic: every workgroup streams the same 1 MiB of dy / x (wrong results, timing only) */
       const unsigned vy = yok ? (2u * (unsigned)c_offy[i]) & 0xfffffu : kDmaOob;
@@ -181,12 +184,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
       // advance this row by BKP pixels
       c_m[i] += BKP;
       c_offy[i] += stepy;
-      c_wo[i] += d_wo;
-      const bool cw = c_wo[i] >= p.Wo;
-      c_wo[i] -= cw ? p.Wo : 0;
-      c_ho[i] += d_ho + (cw ? 1 : 0);
-      const bool ch = c_ho[i] >= p.Ho;
-      c_ho[i] -= ch ? p.Ho : 0;
+      const int wi = c_wi[i] + d_wo_s;
+      const bool cw = wi >= wi_lim;
+      c_wi[i] = wi - (cw ? wrap_w : 0);
+      const int hi = c_hi[i] + d_ho_s + (cw ? p.stride : 0);
+      const bool ch = hi >= hi_lim;
+      c_hi[i] = hi - (ch ? wrap_h : 0);
       c_offx[i] += stepx0 + (cw ? stepx_w : 0) + (ch ? stepx_h : 0);
     }
   };
