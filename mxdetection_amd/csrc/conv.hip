@@ -180,8 +180,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
 #pragma unroll
     for (int i = 0; i < GB; ++i)
+#ifndef MXDET_ABL_NOLOAD
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16,
                                                (int)(2u * (unsigned)wrow[i]), so_b, 0, 0);
+#else
+      asm volatile("" ::"v"(wrow[i]), "s"(so_b));
+#endif
   };
   if constexpr (TAPS > 0) {
 #pragma unroll
@@ -489,7 +493,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       if (TAPS != 1) vo = ((a_mask[i] >> tap) & 1u) ? vo : kDmaOob;
       // a dummy stage has no displacement: its tap-(0,0) address may lie in front of the tensor -- it loads nothing
       if (!live) vo = kDmaOob;
+#ifndef MXDET_ABL_NOLOAD
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xs, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, so_a, 0, 0);
+#else
+      asm volatile("" ::"v"(vo), "s"(so_a));
+#endif
     }
   };
   // fragment addresses: two per operand (the two 32-deep halves differ in the swizzled chunk), rows i / j at +2 KiB each
@@ -795,6 +803,324 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 #endif
 }
 
+// ---- 3x3 / stride 1 / pad 1 with TAP REUSE (forward and data gradient) --------------------------------------------------
+// The static-tap loop above is, on the 64-row tiles, bound by the CU's vector-memory path: 64 B/clk move 16 KiB per
+// step while the step's MFMAs need half of those cycles. The three taps (kh, 0..2) of a 3x3 read the SAME pixels shifted
+// by one: here the gathered operand of a (channel slice, kh) is loaded ONCE as a super-tile of BM + 2 consecutive pixels
+// (BM + 8 rows of 128 B, 8 rows per LDS-DMA piece) and tap kw multiplies rows kw .. kw + BM - 1 of it. Rows whose tap
+// falls off the map (the linear shift wraps to the neighbouring row / image there) are zeroed in the FRAGMENT registers
+// (a per-lane 9-bit tap mask, four v_cndmask per fragment half). Bytes per three taps: (BM + 8 + 3 BN) x 128 instead of
+// 3 (BM + BN) x 128 -- 41 KiB for 3.1 MFLOP at 128 x 64, which the MFMAs, not the memory path, bound.
+//   LDS: gathered super-tile double-buffered (stage = (slice, kh)), filter tiles a ring of three single taps.
+//   Step t (one tap): wait + barrier; fragment reads; issue the filter tile of tap t+2 and, at kw = 0, the super-tile of
+//   the next (slice, kh); masks; 2 x MT x NT MFMAs. Piece counts differ by wave (wave 0 takes the odd super-tile piece):
+//   the counted vmcnt of each unrolled step is chosen per wave.
+template <int BM, int BN, int WM, int WN, bool DGRAD>
+__device__ __forceinline__ void conv3x3_tr_tile(const ConvP& p, int bid, const int nwg) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int AROWS = BM + 8, AP = AROWS / 8;           // super-tile rows / pieces
+  constexpr int APW = (AP + NW - 1) / NW;                 // most pieces a wave takes (waves < AP % NW take one more than the rest)
+  constexpr int APLO = AP / NW;                           // fewest
+  constexpr int ABYTES = AROWS * 128, BBYTES = BN * 128;
+  constexpr int BPW = BN / 8 / NW;                        // filter pieces per wave per tap
+  static_assert(BN % (8 * NW) == 0 && MT % 2 == 0, "tile shape");
+  constexpr int EP_STRIDE = WTN + 4;
+  constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
+  constexpr int MAIN_BYTES = 2 * ABYTES + 3 * BBYTES;
+  constexpr int SMEM_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
+  uint16_t* smem = (uint16_t*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int m0 = p.m_begin + tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int W = p.Wd, H = p.Hd, C = p.C;                  // stride 1, pad 1: source and destination maps coincide
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int Ktot = 9 * C;
+  const int nslices = C >> 6;
+
+  // ---- filter pieces: wave w, piece k covers filter rows 8 (w BPW + k) .. +7 of the tile -------------------------------
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.w, 2u * (unsigned)p.Ncols * (unsigned)Ktot);
+  unsigned vob[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) {
+    const int rb = (wid * BPW + k) * 8 + lrow;
+    int n = n0 + rb;
+    n = n < p.Ncols ? n : p.Ncols - 1;
+    vob[k] = 2u * (unsigned)(n * Ktot + ((lslot ^ ((rb >> 1) & 7)) << 3));
+  }
+  auto issue_b = [&](int slot, int tap, int c0, bool live) {            // slot, tap: constants after unrolling
+    const int so = live ? 2 * (tap * C + c0) : 0;
+#pragma unroll
+    for (int k = 0; k < BPW; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem_raw + 2 * ABYTES + slot * BBYTES + (wid * BPW + k) * 1024),
+                                               16, (int)vob[k], so, 0, 0);
+  };
+  // the first two filter tiles go out before the geometry (cold weights land underneath it)
+  issue_b(0, 0, 0, true);
+  issue_b(1, 1, 0, true);
+
+  // ---- super-tile pieces: wave w takes pieces w, w + NW, ... ; lane -> row 8 piece + lrow ------------------------------
+  // Row r of the super-tile of stage (slice, kh) is the source pixel m0 - 1 + r + (kh - 1) W (forward) or
+  // m0 - 1 + r + (1 - kh) W (data gradient, whose tap kw reads row j + 2 - kw). The descriptor starts (W + 1) pixels
+  // before the tensor: the per-lane offset (m0 + r) C is then non-negative and the stage's uniform part
+  // (kh W C + slice, or (2 - kh) W C + slice) rides in the scalar offset. A lane whose pixel lies outside the tensor loads nothing.
+  const int bias_el = (W + 1) * C;
+  const __amdgpu_buffer_rsrc_t rsrc_xs = make_rsrc(p.x - bias_el, 2u * (unsigned)p.M * (unsigned)C + 2u * (unsigned)bias_el);
+  unsigned voa[APW];
+  unsigned aval[APW];                                      // bit kh: this row's pixel of stage kh is inside the tensor
+#pragma unroll
+  for (int k = 0; k < APW; ++k) {
+    const int piece = wid + k * NW;
+    const int r = piece * 8 + lrow;
+    voa[k] = 2u * (unsigned)((m0 + r) * C + ((lslot ^ ((r >> 1) & 7)) << 3));
+    unsigned v = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int s = m0 - 1 + r + (DGRAD ? 1 - kh : kh - 1) * W;
+      if (piece < AP && s >= 0 && s < p.M) v |= 1u << kh;
+    }
+    aval[k] = v;
+  }
+  auto issue_a = [&](int buf, int kh, int c0, bool live) {              // buf, kh: constants after unrolling
+    const int so = live ? 2 * ((DGRAD ? 2 - kh : kh) * W * C + c0) : 0;
+#pragma unroll
+    for (int k = 0; k < APW; ++k) {
+      if (k == APW - 1 && APW != APLO && wid >= AP % NW) break;        // wave-uniform: this wave has one piece fewer
+      const unsigned vo = (live && ((aval[k] >> kh) & 1u)) ? voa[k] : kDmaOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xs, (lptr_t)(smem_raw + buf * ABYTES + (wid + k * NW) * 1024), 16, (int)vo,
+                                               so, 0, 0);
+    }
+  };
+
+  // ---- per-lane tap masks of the fragment rows ---------------------------------------------------------------------------
+  unsigned tmask[MT];
+  {
+    const int hw = H * W;
+    const float rcp_hw = 1.0f / (float)hw, rcp_w = 1.0f / (float)W;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + frow;
+      unsigned mk = 0;
+      if (m < p.M) {
+        int rem, w;
+        (void)fast_divmod(m, hw, rcp_hw, &rem);
+        const int h = fast_divmod(rem, W, rcp_w, &w);
+        // forward: tap (kh, kw) reads (h + kh - 1, w + kw - 1); data gradient: (h + 1 - kh, w + 1 - kw)
+        const unsigned up = h >= 1 ? 1u : 0u, dn = h + 1 < H ? 1u : 0u, lf = w >= 1 ? 1u : 0u, rt = w + 1 < W ? 1u : 0u;
+        const unsigned rowm = DGRAD ? (dn | 2u | (up << 2)) : (up | 2u | (dn << 2));
+        const unsigned colm = DGRAD ? (rt | 2u | (lf << 2)) : (lf | 2u | (rt << 2));
+        mk = ((rowm & 1u) ? colm : 0u) | (colm << 3) | ((rowm & 4u) ? colm << 6 : 0u);
+      }
+      tmask[i] = mk;
+    }
+  }
+  issue_a(0, 0, 0, true);
+
+  // fragment addresses (elements): row j + shift of the super-tile, shift = kw (forward) / 2 - kw (data gradient)
+  int fa[3][2];
+#pragma unroll
+  for (int sh = 0; sh < 3; ++sh) {
+    fa[sh][0] = lds_off(wm * WTM + frow + sh, fq);
+    fa[sh][1] = lds_off(wm * WTM + frow + sh, 4 + fq);
+  }
+  const int fb0 = lds_off(wn * WTN + frow, fq), fb1 = lds_off(wn * WTN + frow, 4 + fq);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the prologue's pieces (the first super-tile went out last)
+  // Issue order of a wave: [B0 B1] [A0] | step 0: [A1] [B2] | step 1: [B3] | step 2: [B4] | step 3: [A2] [B5] | ...
+  // Step t needs B_t (and, at kw = 0, the super-tile issued three steps earlier, which precedes B_t): everything issued
+  // after B_t may still be in flight = B_{t+1}, plus the super-tile issued in the previous step when that one had kw = 0.
+  for (int cs = 0; cs < nslices; cs += 2) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      if (cs + sl >= nslices) break;                       // wave-uniform (odd slice count)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int kh = tp / 3, kw = tp % 3;                // constants after unrolling
+        const int stage = sl * 3 + kh;                     // parity = super-tile buffer
+        const int t9 = sl * 9 + tp;                        // filter ring slot = t9 % 3
+        if (kw == 1) {
+          if (wid < AP % NW || APW == APLO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + APW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + APLO) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint16_t* sa = smem + (stage & 1) * (ABYTES / 2);
+        const uint16_t* sb = smem + ABYTES + (t9 % 3) * (BBYTES / 2);
+        const int sh = DGRAD ? 2 - kw : kw;
+        bf16x8_t af0[MT], af1[MT], bf0[NT], bf1[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af0[i] = *(const bf16x8_t*)(sa + fa[sh][0] + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf0[j] = *(const bf16x8_t*)(sb + fb0 + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af1[i] = *(const bf16x8_t*)(sa + fa[sh][1] + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf1[j] = *(const bf16x8_t*)(sb + fb1 + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kw == 0) {                                     // the super-tile of the next (slice, kh)
+          const int nst = stage + 1;                       // its buffer: (stage + 1) & 1
+          const int nkh = (kh + 1) % 3, nslice = cs + sl + (kh + 1) / 3;
+          issue_a(nst & 1, nkh, nslice * 64, nslice < nslices);
+        }
+        {
+          const int nt = tp + 2;                           // filter tile two taps ahead
+          const int ntap = nt % 9, nslice = cs + sl + nt / 9;
+          issue_b((t9 + 2) % 3, ntap, nslice * 64, nslice < nslices);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // rows whose tap falls off the map multiply zeros
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const bool ok = (tmask[i] >> tp) & 1u;
+          u32x4_t a0 = __builtin_bit_cast(u32x4_t, af0[i]), a1 = __builtin_bit_cast(u32x4_t, af1[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a0[e] = ok ? a0[e] : 0u; a1[e] = ok ? a1[e] : 0u; }
+          af0[i] = __builtin_bit_cast(bf16x8_t, a0);
+          af1[i] = __builtin_bit_cast(bf16x8_t, a1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail loads before LDS is re-used
+  __syncthreads();
+
+  // ---- epilogue (as conv_igemm_tile, plain rows) ---------------------------------------------------------------------------
+  float* ep = (float*)smem_raw + wid * 32 * EP_STRIDE;
+  constexpr int LPR = WTN / 8;
+  constexpr int RPP = 64 / LPR;
+  constexpr int PASSES = 32 / RPP;
+  const int rl = lane / LPR, cg = lane - rl * LPR;
+  const int col = n0 + wn * WTN + cg * 8;
+  const bool colok = col < p.Ncols;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (p.bias) {
+    const int cb = colok ? col : 0;
+    b0 = *(const float4*)(p.bias + cb);
+    b1 = *(const float4*)(p.bias + cb + 4);
+  }
+#pragma unroll
+  for (int h = 0; h < MT / 2; ++h) {
+    size_t pixs[PASSES];
+    bool oks[PASSES];
+    uint4 rres[PASSES], rmsk[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = ps * RPP + rl;
+      const int m = m0 + wm * WTM + h * 32 + row;
+      oks[ps] = m < p.M && colok;
+      pixs[ps] = oks[ps] ? (size_t)m : 0;
+    }
+    if (p.res) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        size_t ri = pixs[ps] * p.Ncols + (oks[ps] ? col : 0);
+        if (p.res_up) {
+          const int m = (int)pixs[ps];
+          int img = m / (p.Hd * p.Wd);
+          int rem = m - img * (p.Hd * p.Wd);
+          int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+          int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
+          ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * p.Ncols + (oks[ps] ? col : 0);
+        }
+        rres[ps] = *(const uint4*)(p.res + ri);
+      }
+    }
+    if (p.mask) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps)
+        rmsk[ps] = *(const uint4*)(p.mask + pixs[ps] * p.Ncols + (oks[ps] ? col : 0));
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(t * 16 + fq * 4 + r) * EP_STRIDE + j * 16 + frow] = acc[2 * h + t][j][r];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = ps * RPP + rl;
+      float4 v0 = *(const float4*)(ep + row * EP_STRIDE + cg * 8);
+      float4 v1 = *(const float4*)(ep + row * EP_STRIDE + cg * 8 + 4);
+      float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+      if (p.res) {
+        const uint4 rv = rres[ps];
+        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        v[4] += __uint_as_float(rv.z << 16); v[5] += __uint_as_float(rv.z & 0xffff0000u);
+        v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
+      }
+      if (p.mask) {
+        const unsigned mm[4] = {rmsk[ps].x, rmsk[ps].y, rmsk[ps].z, rmsk[ps].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          unsigned lo = mm[k] & 0xffffu, hi = mm[k] >> 16;
+          if (!(lo != 0u && lo < 0x8000u)) v[2 * k] = 0.0f;
+          if (!(hi != 0u && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
+        }
+      }
+      if (p.relu && !p.mask) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+      }
+      uint4 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      o.z = pack_bf16x2(v[4], v[5]);
+      o.w = pack_bf16x2(v[6], v[7]);
+      if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool DGRAD>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv3x3_tr_kernel(ConvP p) {
+  conv3x3_tr_tile<BM, BN, WM, WN, DGRAD>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int BM, int BN, int WM, int WN, bool DGRAD>
+static int launch_tr(ConvP& p, hipStream_t s) {
+  if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);
+  p.tiles_n = ceil_div(p.Ncols, BN);
+  const long long nwg = (long long)p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((conv3x3_tr_kernel<BM, BN, WM, WN, DGRAD>), dim3((unsigned)nwg), dim3(64 * WM * WN), 0, s, p);
+  return check_launch("conv2d");
+}
+
 template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
@@ -898,6 +1224,12 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
 // Tile choice (measured on MI355X, tools/bench_one_conv.py sweeps, profiles/r01_conv_cfg_sweep.txt): what matters
 // most is having 2-3 workgroups resident per CU so that one workgroup's barrier / LDS-latency / DMA-issue phases
 // overlap another's MFMA phase; a 2-stage ring (48-64 KiB of LDS) allows that, deeper rings do not pay.
+// the tap-reuse kernel's geometry: 3x3, stride 1, pad 1, maps at least 8 wide, whole 64-channel slices
+static bool tr_ok(const ConvP& p) {
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Wd >= 8 && p.C % 64 == 0 && p.m_begin == 0 &&
+         p.Hd == p.Hs && p.Wd == p.Ws;
+}
+
 template <bool DGRAD>
 static int launch(ConvP& p, hipStream_t s) {
   const int force = g_force_cfg;
@@ -936,6 +1268,10 @@ static int launch(ConvP& p, hipStream_t s) {
     case 43: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 9>(p, s);
     case 44: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 9>(p, s);
     case 45: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
+    case 50: if (tr_ok(p)) return launch_tr<128, 64, 4, 1, DGRAD>(p, s); break;   // other layers: the heuristic
+    case 51: if (tr_ok(p)) return launch_tr<64, 64, 2, 2, DGRAD>(p, s); break;
+    case 52: if (tr_ok(p)) return launch_tr<128, 64, 4, 2, DGRAD>(p, s); break;   // 8 waves, 32 x 32 per wave
+    case 53: if (tr_ok(p)) return launch_tr<128, 128, 4, 2, DGRAD>(p, s); break;  // 8 waves, 32 x 64 per wave, 84 KiB
     case 41: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
     // half-stage pipeline (NS = 1) variants
     case 20: return launch_cfg<64, 64, 2, 2, 1, DGRAD>(p, s);
