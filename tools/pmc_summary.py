@@ -22,7 +22,8 @@ def family(name):
         args = [a.strip() for a in m.group(2).split(",")]
         return ("conv_igemm_dgrad" if args[5] == "true" else "conv_igemm_fwd") + " %sx%s" % (args[0], args[1]) + ("g" if m.group(1) else "")
     for key in ("wgrad_grouped_big_kernel", "wgrad_grouped_kernel", "wgrad_reduce_grouped_kernel", "wgrad_kernel", "stem_pool_kernel",
-                "roi_align_bwd_gather_kernel", "roi_bwd_tab_kernel", "roi_bwd_rows_kernel", "roi_align_fwd_kernel", "sgd_kernel",
+                "roi_align_bwd_gather_kernel", "roi_bwd_tab_kernel", "roi_bwd_rows_kernel", "roi_bwd_seg_kernel", "roi_bwd_box_kernel",
+                "roi_align_fwd_kernel", "sgd_kernel",
                 "filter_transpose_batched_kernel", "nms_scan_rows_kernel", "nms_mask_kernel", "proposal_", "anchor_", "rpn_loss_kernel",
                 "rcnn_loss_kernel", "upsample2_bwd_kernel", "proposal_target_kernel"):
         if key in n:
