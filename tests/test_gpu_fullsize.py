@@ -136,6 +136,53 @@ def test_full_size_retina_detect_bit_exact(hip, oracle):
     assert np.array_equal(dets.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_full_size_mask_branch_bit_exact(hip, oracle):
+    """Mask R-CNN R50-FPN (BASELINE config 4) at the benchmark shape: the mask branch's rois / matched GT come from the
+    full-size box branch; mask targets resampled from 2 x 16 instance masks of 800 x 1344, the 14 x 14 RoIAlign on the
+    200 x 336 pyramid, and the per-pixel BCE loss + gradient on the 28 x 28 x 80 logits, against the oracle."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mxdetection_amd.models import FasterRCNN
+    m = FasterRCNN("cuda", depth=50, seed=7, with_mask=True)
+    img, gt, info = bench.synth_batch(0, 2, "cuda")
+    H, W = img.shape[2], img.shape[3]
+    assert (H, W) == (800, 1344)
+    b = gt[:, :16]
+    yy = torch.arange(H, device="cuda").view(1, 1, H, 1).float()
+    xx = torch.arange(W, device="cuda").view(1, 1, 1, W).float()
+    cx, cy = 0.5 * (b[..., 0] + b[..., 2]), 0.5 * (b[..., 1] + b[..., 3])
+    rx, ry = 0.5 * (b[..., 2] - b[..., 0]) + 0.5, 0.5 * (b[..., 3] - b[..., 1]) + 0.5
+    masks = ((((xx - cx[..., None, None]) / rx[..., None, None]) ** 2 + ((yy - cy[..., None, None]) / ry[..., None, None]) ** 2) <= 1.0)
+    masks = (masks & (b[..., 4] >= 0)[..., None, None]).to(torch.uint8).contiguous()
+    m.forward_backward(img, gt, info, step=5, image_offset=0, gt_masks=masks)
+    torch.cuda.synchronize()
+    mh = m.mask_head
+    rois = mh.rois.cpu().numpy().reshape(-1, 5)
+    matched, labels = mh.matched.cpu().numpy(), mh.roi_labels.cpu().numpy()
+    R = rois.shape[0]
+    assert R == 2 * mh.Rimg and int((labels > 0).sum()) >= 8            # real foreground rois (random-init proposals: a few per GT)
+    # (1) targets: instance-mask crop / resample to 28 x 28, bit-exact
+    w_tg, w_cls = oracle.mask_target(rois, matched, labels, masks.cpu().numpy(), mh.S)
+    assert np.array_equal(mh.cls.cpu().numpy(), w_cls)
+    assert np.array_equal(mh.tg.cpu().numpy(), w_tg)
+    assert 0.05 < w_tg[w_cls > 0].mean() < 0.95
+    # (2) 14 x 14 RoIAlign of the mask branch on the full pyramid, bit-exact
+    ex = m.mask_roi_extractor
+    feats = [_bits(f) for f in ex.feats]
+    assert feats[0].shape == (2, 200, 336, 256)
+    lv = ex.levels.cpu().numpy()
+    assert np.array_equal(lv, oracle.fpn_level(rois))
+    want = oracle.roi_align(feats, ex.scales, rois, lv, 14, 14, 2)
+    assert np.array_equal(_bits(ex.out), want)
+    # (3) loss + gradient on the head's actual logits
+    logits = mh.o.float().cpu().numpy()
+    assert logits.shape[:3] == (R, 28, 28)
+    w_loss, w_grad = oracle.mask_loss(logits, w_cls, w_tg)
+    assert np.allclose(mh.loss.cpu().numpy(), w_loss, rtol=2e-5)
+    assert np.array_equal(_bits(mh.go), oracle.f32_to_bf16_bits(w_grad))
+
+
 def test_full_size_exchange_schedule_over_rccl_world1(hip):
     """The N > 1 schedule (graph segments cut at five buckets, side-stream weight-gradient graphs, per-bucket update
     graphs, the exchange through mxdet_allreduce_bucket) at the benchmark shape, over RCCL at world size 1: it must take
