@@ -183,6 +183,58 @@ def test_full_size_mask_branch_bit_exact(hip, oracle):
     assert np.array_equal(_bits(mh.go), oracle.f32_to_bf16_bits(w_grad))
 
 
+def test_full_size_retinanet_targets_and_loss(hip, oracle):
+    """RetinaNet R101-FPN (BASELINE config 5) training path at the benchmark shape: dense assignment of all 201,600 anchors
+    (no subsampling, border check off), class labels, and the fused focal + smooth-L1 loss of every level on the head's
+    real outputs, against the oracle (labels / matched / targets bit-exact; losses within the fp32-vs-float64 sum bound;
+    classification gradient of the finest level within bf16 storage)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mxdetection_amd.models import RetinaNet
+    m = RetinaNet("cuda", depth=101, seed=7)
+    img, gt, info = bench.synth_batch(0, 3, "cuda")
+    m.forward_backward(img, gt, info, step=2, image_offset=0)
+    torch.cuda.synchronize()
+    hd = m.head
+    A, Cn = hd.A, hd.Cn
+    anchors = hd.anchors.cpu().numpy()
+    assert anchors.shape == (201600, 4)
+    gt_np, info_np = gt.cpu().numpy(), info.cpu().numpy()
+    w_lab, w_mg, w_tg, _ = oracle.anchor_target(anchors, gt_np, info_np, hd.fg_thresh, hd.bg_thresh, 1.0e6, 0, 0.5, 0, 0, 0)
+    lab, mg, tg, _ = [t.cpu().numpy() for t in hd.at_out]
+    assert np.array_equal(lab, w_lab) and int((w_lab == 1).sum()) > 50
+    fg = w_lab == 1
+    assert np.array_equal(mg[fg], w_mg[fg])
+    assert np.array_equal(tg.view(np.uint32), w_tg.view(np.uint32))
+    cls_lab = np.where(fg, gt_np[np.arange(2)[:, None], w_mg, 4].astype(np.int32), w_lab)
+    assert np.array_equal(hd.cls_labels.cpu().numpy(), cls_lab)
+    nfg = int(fg.sum())
+    assert int(hd.num_fg) == nfg
+    # losses: sum over levels of focal (normalised by the global fg count) and smooth-L1
+    tot_cls = tot_box = 0.0
+    for l in range(len(hd.co)):
+        co = hd.co[l].float().cpu().numpy()
+        bo = hd.bo[l].float().cpu().numpy()
+        N, H, W = co.shape[:3]
+        off = hd.level_offsets[l]
+        lv = cls_lab[:, off:off + H * W * A].reshape(-1)
+        w_loss, w_grad = oracle.focal_loss(co[..., :A * Cn].reshape(-1, Cn), lv, hd.alpha, hd.gamma)
+        lvl_fg = max(1, int((lv > 0).sum()))
+        tot_cls += float(w_loss[0]) * lvl_fg / max(1, nfg)
+        d = bo[..., :4 * A].reshape(-1, 4)
+        tv = w_tg[:, off:off + H * W * A].reshape(-1, 4)
+        f = lv > 0
+        if f.any():
+            l1, _ = oracle.smooth_l1(d[f], tv[f], None, hd.sigma)
+            tot_box += float(l1.sum()) / max(1, nfg)
+        if l == 0:
+            g = hd.gco[0].float().cpu().numpy()[..., :A * Cn].reshape(-1, Cn)
+            assert np.allclose(g, w_grad * lvl_fg / max(1, nfg), rtol=1e-2, atol=1e-7)
+    got = hd.loss.cpu().numpy()
+    assert np.allclose(got[0], tot_cls, rtol=1e-4) and np.allclose(got[1], tot_box, rtol=1e-4), (got, tot_cls, tot_box)
+
+
 def test_full_size_exchange_schedule_over_rccl_world1(hip):
     """The N > 1 schedule (graph segments cut at five buckets, side-stream weight-gradient graphs, per-bucket update
     graphs, the exchange through mxdet_allreduce_bucket) at the benchmark shape, over RCCL at world size 1: it must take
