@@ -22,6 +22,12 @@ class BBoxHead:
         self.fc_out = ConvLayer("bbox.fc_out", fc_dim, self.ld, 1, init_std=0.01, cout_real=num_classes + self.reg_dim, **kw)
         self.fc2 = ConvLayer("bbox.fc2", fc_dim, fc_dim, 1, **kw)
         self.fc1 = ConvLayer("bbox.fc1", in_features, fc_dim, 1, **kw)
+        # checkpoint layout (DetectorBase._to_mx): fully connected layers are stored 2-D; fc1's input is the pooled
+        # [7,7,C] block flattened (H, W, C) here and (C, H, W) in an MXNet FullyConnected after a Flatten of NCHW
+        pooled = 7
+        self.fc1.fc_in_hwc = (pooled, pooled, in_features // (pooled * pooled)) if in_features % (pooled * pooled) == 0 else ()
+        self.fc2.fc_in_hwc = ()
+        self.fc_out.fc_in_hwc = ()
         self.R, self.fg_fraction, self.fg_thresh, self.bg_hi, self.bg_lo = rois_per_image, fg_fraction, fg_thresh, bg_hi, bg_lo
         self.stds, self.sigma, self.seed, self.device = stds, sigma, seed, device
         self.in_features, self.fc_dim = in_features, fc_dim

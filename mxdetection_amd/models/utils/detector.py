@@ -59,9 +59,9 @@ class DetectorBase:
     # ---- checkpoints: MXNet NDArray-list container, MXNet tensor layouts ----
 
     def _named_tensors(self):
-        """(name, kind, tensor) of every stored parameter: trainable master weights (fp32 arena views), frozen filters
-        (bf16) and folded frozen-BN shifts (fp32)."""
-        out = [("stem.weight", "frozen", self.backbone.stem_w), ("stem.bias", "frozen", self.backbone.stem_b)]
+        """(name, kind, tensor, layer) of every stored parameter: trainable master weights (fp32 arena views), frozen
+        filters (bf16) and folded frozen-BN shifts (fp32). layer is the owning ConvLayer (None for the stem)."""
+        out = [("stem.weight", "frozen", self.backbone.stem_w, None), ("stem.bias", "frozen", self.backbone.stem_b, None)]
         frozen = [l for st in self.backbone.stages for b in st for l in b.layers() if not l.trainable]
         seen = set()
         for l in list(self.layers) + frozen:
@@ -69,48 +69,88 @@ class DetectorBase:
                 continue
             seen.add(id(l))
             if l.trainable:
-                out.append((l.name + ".weight", "w", self.arena.view(l.wi, "w")))
+                out.append((l.name + ".weight", "w", self.arena.view(l.wi, "w"), l))
                 if l.train_bias:
-                    out.append((l.name + ".bias", "w", self.arena.view(l.bi, "w")))
+                    out.append((l.name + ".bias", "w", self.arena.view(l.bi, "w"), l))
                 elif l.has_bias:
-                    out.append((l.name + ".bias", "frozen", l.frozen_bias))
+                    out.append((l.name + ".bias", "frozen", l.frozen_bias, l))
             else:
-                out.append((l.name + ".weight", "frozen", l.w_bf16))
+                out.append((l.name + ".weight", "frozen", l.w_bf16, l))
                 if l.has_bias:
-                    out.append((l.name + ".bias", "frozen", l.bias_f32))
+                    out.append((l.name + ".bias", "frozen", l.bias_f32, l))
+        return out
+
+    @staticmethod
+    def _to_mx(t, layer):
+        """This repo's tensor -> the array MXNet stores for the same parameter: alignment-padding output channels
+        (rows past cout_real: fused / padded head outputs) are dropped; convolution filters [O,KH,KW,I] -> OIHW;
+        fully connected layers (`fc_in_hwc` set: a 1x1 'convolution' over flattened features) -> 2-D [O, I], with the
+        input axis reordered from this repo's (H, W, C) flatten to MXNet's (C, H, W) when the input was spatial."""
+        real = layer.cout_real if layer is not None else t.shape[0]
+        t = t[:real].float()
+        if t.dim() == 4:
+            hwc = getattr(layer, "fc_in_hwc", None) if layer is not None else None
+            if hwc is not None:
+                O = t.shape[0]
+                if len(hwc) == 3:
+                    t = t.reshape(O, *hwc).permute(0, 3, 1, 2)
+                t = t.reshape(O, -1)
+            else:
+                t = t.permute(0, 3, 1, 2)
+        return t.contiguous().cpu().numpy()
+
+    @staticmethod
+    def _from_mx(a, like, layer):
+        """Inverse of _to_mx onto a tensor shaped like `like` (padding channels zero)."""
+        src = torch.from_numpy(a).to(like.device)
+        if like.dim() == 4:
+            hwc = getattr(layer, "fc_in_hwc", None) if layer is not None else None
+            if hwc is not None:
+                O = src.shape[0]
+                if len(hwc) == 3:
+                    src = src.reshape(O, hwc[2], hwc[0], hwc[1]).permute(0, 2, 3, 1)
+                src = src.reshape(O, 1, 1, -1)
+            else:
+                src = src.permute(0, 2, 3, 1)
+        out = torch.zeros(like.shape, dtype=torch.float32, device=like.device)
+        assert tuple(src.shape[1:]) == tuple(like.shape[1:]) and src.shape[0] <= like.shape[0], \
+            "checkpoint %s vs model %s" % (tuple(src.shape), tuple(like.shape))
+        out[:src.shape[0]] = src
         return out
 
     def save_checkpoint(self, path):
-        """Write every parameter ("arg:<name>", filters in MXNet's OIHW layout, fp32) and the SGD momentum of the
-        trainable ones ("aux:momentum:<name>") as an MXNet 1.3.0 `.params` file (utils/params_io.py)."""
+        """Write every parameter ("arg:<name>", fp32, in the layout MXNet keeps it in: convolution filters OIHW, fully
+        connected weights 2-D [out, C*H*W], alignment padding stripped -- see _to_mx) and the SGD momentum of the
+        trainable ones ("aux:momentum:<name>") as an MXNet 1.3.0 `.params` file (utils/params_io.py). The byte layout
+        of the container is this repo's reading of MXNet's NDArray::Save; no MXNet-written file exists here to pin it."""
         from ...utils import save_params
-        to_mx = lambda t: (t.permute(0, 3, 1, 2) if t.dim() == 4 else t).float().contiguous().cpu().numpy()  # noqa: E731
         blob = {}
-        for name, kind, t in self._named_tensors():
-            blob["arg:" + name] = to_mx(t)
+        by_name = {}
+        for name, kind, t, layer in self._named_tensors():
+            blob["arg:" + name] = self._to_mx(t, layer)
+            by_name[name] = layer
         for i, e in enumerate(self.arena.entries):
-            blob["aux:momentum:" + e[0]] = to_mx(self.arena.view(i, "m"))
+            blob["aux:momentum:" + e[0]] = self._to_mx(self.arena.view(i, "m"), by_name.get(e[0]))
         save_params(path, blob)
 
     def load_checkpoint(self, path, strict=True):
         """Inverse of save_checkpoint; refreshes the bf16 / transposed working copies. Returns the names not found."""
         from ...utils import load_params
         blob = load_params(path)
-        from_mx = lambda a, like: torch.from_numpy(a).to(like.device).permute(0, 2, 3, 1) if a.ndim == 4 else torch.from_numpy(a).to(like.device)  # noqa: E731,E501
         missing = []
-        for name, kind, t in self._named_tensors():
+        by_name = {}
+        for name, kind, t, layer in self._named_tensors():
+            by_name[name] = layer
             a = blob.get("arg:" + name)
             if a is None:
                 missing.append(name)
                 continue
-            src = from_mx(a, t)
-            assert tuple(src.shape) == tuple(t.shape), "%s: checkpoint %s vs model %s" % (name, tuple(src.shape), tuple(t.shape))
-            t.copy_(src.to(t.dtype))
+            t.copy_(self._from_mx(a, t, layer).to(t.dtype))
         for i, e in enumerate(self.arena.entries):
             a = blob.get("aux:momentum:" + e[0])
             if a is not None:
                 m = self.arena.view(i, "m")
-                m.copy_(from_mx(a, m))
+                m.copy_(self._from_mx(a, m, by_name.get(e[0])))
         if strict and missing:
             raise KeyError("checkpoint lacks %d parameters, e.g. %s" % (len(missing), missing[:3]))
         self.arena.refresh_bf16()

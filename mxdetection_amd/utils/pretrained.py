@@ -42,7 +42,7 @@ def load_pretrained_backbone(model, params, depth=50, names=None, eps=2e-5, fix_
     blob = load_params(params) if isinstance(params, (str, bytes)) else params
     if not isinstance(blob, dict):
         raise ValueError("the .params file carries no names (NDArray list), cannot map it onto the backbone")
-    tensors = {n: t for n, _, t in model._named_tensors()}
+    tensors = {n: t for n, _, t, _ in model._named_tensors()}
     missing = []
     for ours, wname, bn in (names or resnet_v1_names(depth)):
         w = _get(blob, wname)

@@ -189,6 +189,12 @@ def test_checkpoint_round_trip(hip, tmp_path):
     blob = load_params(fn)
     assert blob["arg:rpn.conv.weight"].shape == (256, 256, 3, 3)            # MXNet OIHW layout on disk
     assert "aux:momentum:bbox.fc1.weight" in blob
+    # fully connected layers are 2-D with MXNet's (C, H, W) input order; alignment padding is not stored
+    assert blob["arg:bbox.fc1.weight"].shape == (1024, 256 * 7 * 7) and blob["arg:bbox.fc2.weight"].shape == (1024, 1024)
+    assert blob["arg:bbox.fc_out.weight"].shape == (81 + 4 * 81, 1024) and blob["arg:bbox.fc_out.bias"].shape == (405,)
+    assert blob["arg:rpn.out.weight"].shape == (15, 256, 1, 1)
+    w_here = a.arena.view(a.bbox_head.fc1.wi, "w").float().cpu().numpy().reshape(1024, 7, 7, 256)
+    assert np.array_equal(blob["arg:bbox.fc1.weight"].reshape(1024, 256, 7, 7)[5, 17, 3, 6], w_here[5, 3, 6, 17])
     b = FasterRCNN("cuda", seed=11, pre_nms_top_n=600, post_nms_top_n=300, rois_per_image=128)
     assert not torch.equal(a.arena.w, b.arena.w)
     assert b.load_checkpoint(fn) == []
