@@ -323,6 +323,14 @@ typedef struct {
 int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w,
                      const float* bias, const uint16_t* residual, uint16_t* y,
                      mxdet_stream_t stream);
+/* Forward with the reduction split over `ksplit` ranges of 64-channel slices, for 1x1 / stride-1 layers with a long
+ * reduction on few rows (fully connected layers on pooled rois): raw fp32 tiles in the caller's workspace, folded in
+ * split order (deterministic) with bias / residual / ReLU by a second kernel. Last-bit different from mxdet_conv2d_fwd
+ * (another summation order); ksplit = 1 is that call. */
+size_t mxdet_conv2d_fwd_splitk_workspace_bytes(const mxdet_conv_desc_t* d, int32_t ksplit);
+int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
+                            const uint16_t* residual, uint16_t* y, int32_t ksplit, void* workspace,
+                            size_t workspace_bytes, mxdet_stream_t stream);
 /* dgrad: dx[N,H,W,Cin] = (sum over taps dy[N,Ho,Wo,Cout] * w  +  residual) * (relu_mask > 0), with
  * wt = the same filter stored [Cin,KH,KW,Cout] (mxdet_filter_transpose). residual (bf16, shape of dx;
  * may be NULL) is the gradient arriving over a parallel branch (identity shortcut / sibling conv);

@@ -44,6 +44,9 @@ struct ConvP {
   int par_hc[2], par_wc[2];  // number of rows / columns of each parity
   int par_h0[2], par_w0[2];  // first coordinate of each parity
   int m_begin;     // first output row of this launch (a layer may be covered by two launches with different tiles)
+  int ksplit;      // > 1 (static 1x1 path only): the grid is ksplit x tiles, split ks multiplies channel slices
+                   // [ks * per, (ks + 1) * per) and writes raw fp32 sums to partial[ks][M][Ncols]
+  float* partial;
   int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
 };
 
@@ -121,9 +124,24 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 
   // XCD-aware tile order: blocks that share an XCD (bid % 8) walk consecutive tiles, and consecutive
   // tiles share their A rows (n fastest), so the A tile is re-read from that XCD's L2.
+  int ks = 0, sl_begin = 0, sl_end = p.C >> 6;     // split-K (static 1x1 path): this workgroup's range of channel slices
+  int nwg_ = nwg;
+  if constexpr (TAPS == 1) {
+    if (p.ksplit > 1) {
+      const int tiles = p.tiles_m * p.tiles_n;       // a multiple of 8 keeps every tile on its XCD (the host checks)
+      ks = bid / tiles;
+      bid -= ks * tiles;
+      nwg_ = tiles;
+      const int per = ((p.C >> 6) + p.ksplit - 1) / p.ksplit;
+      sl_begin = ks * per;
+      sl_end = sl_begin + per < sl_end ? sl_begin + per : sl_end;
+      sl_end = sl_end < sl_begin ? sl_begin : sl_end;
+    }
+  }
   if constexpr (!PAR) {   // PAR: classes differ 4:2:2:1 in work and are laid out one after the other -- giving each XCD
                           // a contiguous range would put all the heavy tiles on two of the eight; keep the hardware's
                           // round-robin instead
+    const int nwg = nwg_;
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -189,7 +207,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   };
   if constexpr (TAPS > 0) {
 #pragma unroll
-    for (int s0 = 0; s0 < NS - 1; ++s0) issue_b(s0, s0 % TAPS, (s0 / TAPS) * 64, s0 < KT);
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+      issue_b(s0, s0 % TAPS, (sl_begin + s0 / TAPS) * 64, s0 < (sl_end - sl_begin) * TAPS);
   }
   int a_off[GA];
   unsigned a_mask[GA];
@@ -505,13 +524,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const uint16_t* fa1 = smem + lds_off(wm * WTM + frow, 4 + fq);
   const uint16_t* fb0 = smem + BM * 64 + lds_off(wn * WTN + frow, fq);
   const uint16_t* fb1 = smem + BM * 64 + lds_off(wn * WTN + frow, 4 + fq);
-  const int nslices = p.C >> 6;
+  const int nslices = sl_end;                     // (split-K: this workgroup's slices are [sl_begin, sl_end))
   // (the prologue's filter pieces went out before the geometry; its gather pieces follow them, so stage 0 is complete
   // once only the later stages' gather pieces are outstanding)
 #pragma unroll
-  for (int s0 = 0; s0 < NS - 1; ++s0) issue_a(s0, s0 % TAPS, (s0 / TAPS) * 64, s0 < KT);
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    issue_a(s0, s0 % TAPS, (sl_begin + s0 / TAPS) * 64, s0 < (sl_end - sl_begin) * TAPS);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * GA) : "memory");
-  for (int cs = 0; cs < nslices; cs += SL) {
+  for (int cs = sl_begin; cs < nslices; cs += SL) {
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       if (SL > 1 && cs + sl >= nslices) break;                        // wave-uniform
@@ -763,6 +783,16 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       const int row = ps * RPP + rl;
       float4 v0 = *(const float4*)(ep + row * EP_STRIDE + cg * 8);
       float4 v1 = *(const float4*)(ep + row * EP_STRIDE + cg * 8 + 4);
+      if constexpr (TAPS == 1) {
+        if (p.ksplit > 1) {                          // split-K: raw sums; bias / residual / ReLU happen in the fold kernel
+          if (oks[ps]) {
+            float* dst = p.partial + ((size_t)ks * p.M + pixs[ps]) * p.Ncols + col;
+            *(float4*)dst = v0;
+            *(float4*)(dst + 4) = v1;
+          }
+          continue;
+        }
+      }
       float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
       if (p.res) {
         const uint4 rv = rres[ps];
@@ -1216,6 +1246,7 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
   if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);   // caller may restrict the row range
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
+  if (TAPS == 1 && p.ksplit > 1) nwg *= p.ksplit;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, KU, TAPS>), dim3((unsigned)nwg), dim3(64 * WM * WN),
                      0, s, p);
   return check_launch("conv2d");
@@ -1383,6 +1414,86 @@ extern "C" int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, c
   p.relu = d->relu; p.res_up = d->res_upsample;
   p.M = d->N * d->Ho * d->Wo;
   return launch<false>(p, as_stream(stream));
+}
+
+// ---- split-K forward for long reductions on few rows (FC6: 1,024 rois x 12,544 features x 1,024 outputs) ----------------
+// 64 x 64 tiles give such a layer 256 workgroups -- one wave per SIMD, 196 latency-bound steps each (118 us in the step, the
+// chip mostly idle). With the reduction cut in `ksplit` ranges the grid is ksplit times larger; the raw fp32 tiles go to
+// the caller's workspace and a fold kernel adds them in split order (deterministic) and applies bias / residual / ReLU.
+namespace mxdet {
+__global__ void __launch_bounds__(256)
+conv_splitk_fold_kernel(const float* __restrict__ partial, int ksplit, long long M, int Ncols, const float* __restrict__ bias,
+                        const uint16_t* __restrict__ res, int relu, uint16_t* __restrict__ y) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;     // element index, 8 channels per lane
+  const long long total = M * Ncols;
+  if (i >= total) return;
+  const int col = (int)(i % Ncols);
+  float v[8];
+  {
+    const float4 a = *(const float4*)(partial + i), b = *(const float4*)(partial + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  for (int k = 1; k < ksplit; ++k) {
+    const float4 a = *(const float4*)(partial + (size_t)k * total + i), b = *(const float4*)(partial + (size_t)k * total + i + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (bias) {
+    const float4 a = *(const float4*)(bias + col), b = *(const float4*)(bias + col + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (res) {
+    const uint4 rv = *(const uint4*)(res + i);
+    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+    v[4] += __uint_as_float(rv.z << 16); v[5] += __uint_as_float(rv.z & 0xffff0000u);
+    v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
+  }
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+  }
+  uint4 o;
+  o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+  *(uint4*)(y + i) = o;
+}
+}  // namespace mxdet
+
+extern "C" size_t mxdet_conv2d_fwd_splitk_workspace_bytes(const mxdet_conv_desc_t* d, int32_t ksplit) {
+  if (!d || ksplit < 1) return 0;
+  return (size_t)ksplit * (size_t)d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
+}
+
+extern "C" int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
+                                       const uint16_t* residual, uint16_t* y, int32_t ksplit, void* workspace,
+                                       size_t workspace_bytes, mxdet_stream_t stream) {
+  clear_error();
+  int rc = validate(d, "conv2d_fwd_splitk");
+  if (rc) return rc;
+  MXDET_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->res_upsample, MXDET_ESHAPE,
+                "conv2d_fwd_splitk: 1x1 / stride 1 / pad 0 layers (fully connected) only");
+  MXDET_REQUIRE(d->Cin % 64 == 0 && d->Cout % 8 == 0, MXDET_ESHAPE, "conv2d_fwd_splitk: Cin %% 64, Cout %% 8");
+  MXDET_REQUIRE(ksplit >= 1 && ksplit <= d->Cin / 64, MXDET_ESHAPE, "conv2d_fwd_splitk: 1 <= ksplit <= Cin / 64");
+  MXDET_REQUIRE(x && w && y, MXDET_EINVAL, "conv2d_fwd_splitk: null pointer");
+  if (ksplit == 1) return mxdet_conv2d_fwd(d, x, w, bias, residual, y, stream);
+  const size_t need = mxdet_conv2d_fwd_splitk_workspace_bytes(d, ksplit);
+  MXDET_REQUIRE(workspace && workspace_bytes >= need, MXDET_EWORKSPACE, "conv2d_fwd_splitk: workspace %zu < %zu", workspace_bytes, need);
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w; p.bias = nullptr; p.res = nullptr; p.mask = nullptr; p.y = y;
+  p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.C = d->Cin;
+  p.Hd = d->Ho; p.Wd = d->Wo; p.Ncols = d->Cout;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+  p.M = d->N * d->Ho * d->Wo;
+  p.ksplit = ksplit; p.partial = (float*)workspace;
+  const long long tiles = (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 64);
+  MXDET_REQUIRE(tiles % 8 == 0, MXDET_ESHAPE, "conv2d_fwd_splitk: the tile count (%lld) must be a multiple of 8", tiles);
+  hipStream_t s = as_stream(stream);
+  rc = launch_cfg<64, 64, 2, 2, 3, false, false, 1, 1>(p, s);
+  if (rc) return rc;
+  const long long total = (long long)p.M * p.Ncols;
+  hipLaunchKernelGGL(conv_splitk_fold_kernel, dim3((unsigned)ceil_div<long long>(total / 8, 256)), dim3(256), 0, s,
+                     (const float*)workspace, ksplit, (long long)p.M, p.Ncols, bias, residual, d->relu, y);
+  return check_launch("conv2d_fwd_splitk");
 }
 
 extern "C" int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy, const uint16_t* wt,

@@ -4,10 +4,13 @@ Plugin slot: models/bbox_heads (/root/reference/README.md:29) with core/bbox + c
 The FCs run on the same MFMA implicit-GEMM kernels as the convolutions (1x1 on [R,1,1,C] tensors); cls and reg
 share one GEMM whose output is padded to 448 columns (a multiple of 64, so dgrad can reduce over it).
 """
+import os
+
 import torch
 
 from ...core import bbox as B_
 from ...core import loss as L_
+from ...ops import dense
 from ..utils.layers import ConvLayer, cached_buf
 
 
@@ -31,6 +34,7 @@ class BBoxHead:
         self.R, self.fg_fraction, self.fg_thresh, self.bg_hi, self.bg_lo = rois_per_image, fg_fraction, fg_thresh, bg_hi, bg_lo
         self.stds, self.sigma, self.seed, self.device = stds, sigma, seed, device
         self.in_features, self.fc_dim = in_features, fc_dim
+        self.fc1_ksplit = int(os.environ.get("MXDET_TUNE_FC1_KSPLIT", "4"))
         self.bufs = {}
 
     def layers(self):
@@ -57,7 +61,16 @@ class BBoxHead:
     def forward(self, pooled):
         R = pooled.shape[0]
         self.x = pooled.view(R, 1, 1, -1)
-        self.h1 = self.fc1.forward(self.x, relu=True, out=self._buf("h1", (R, 1, 1, self.fc_dim)))
+        # fc1 is 196 K-steps on 16 x 16 tiles of 64 x 64: one latency-bound wave per SIMD on its own (118 us in the step
+        # while nothing else runs). Split four ways the grid fills the chip; the fold is deterministic (split order).
+        ks = self.fc1_ksplit if (R * self.fc_dim) % (64 * 64 * 8) == 0 and R % 64 == 0 else 1
+        if ks > 1:
+            need = 4 * ks * R * self.fc_dim
+            ws = self._buf("fc1_ws", (need,), dtype=torch.uint8)
+            self.h1 = dense.conv2d_forward_splitk(self.x, self.fc1.w_bf16, self.fc1.bias_f32, None, True, ks,
+                                                  self._buf("h1", (R, 1, 1, self.fc_dim)), ws)
+        else:
+            self.h1 = self.fc1.forward(self.x, relu=True, out=self._buf("h1", (R, 1, 1, self.fc_dim)))
         self.h2 = self.fc2.forward(self.h1, relu=True, out=self._buf("h2", (R, 1, 1, self.fc_dim)))
         self.o = self.fc_out.forward(self.h2, out=self._buf("o", (R, 1, 1, self.ld)))
         return self.o

@@ -32,6 +32,22 @@ def conv2d_forward(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, 
     return out
 
 
+def conv2d_forward_splitk(x, w, bias=None, residual=None, relu=False, ksplit=4, out=None, workspace=None):
+    """1x1 / stride-1 forward with the reduction split `ksplit` ways (long reductions on few rows: FC6)."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    d = conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0, relu, False)
+    if out is None:
+        out = torch.empty((N, d.Ho, d.Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    need = lib.mxdet_conv2d_fwd_splitk_workspace_bytes(C.byref(d), ksplit)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=x.device)
+    check(lib.mxdet_conv2d_fwd_splitk(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), ksplit, ptr(workspace),
+                                      workspace.numel(), stream_ptr()), "conv2d_fwd_splitk")
+    return out
+
+
 def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None):
     """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter)."""
     lib = _lib.load()

@@ -464,3 +464,26 @@ def test_layer_gradients_vs_torch_fp32(hip, oracle, Cin, Cout, K, stride):
     got = dx.float().cpu().numpy()
     assert rel(got, want) <= 1e-3, rel(got, want)
     assert float((got != want).mean()) < 0.02
+
+
+def test_conv_fwd_splitk_vs_torch(hip):
+    """Split-K forward (FC-type layers): raw fp32 tiles + deterministic fold, against torch fp32 on the same bf16 operands
+    and against the unsplit kernel (same result up to fp32 summation order); bias, residual and ReLU go through the fold."""
+    import torch
+    from mxdetection_amd.ops import dense
+    g = torch.Generator(device="cuda").manual_seed(5)
+    R, Cin, Cout = 512, 1600, 256          # 32 tiles; 25 slices over 4 splits: uneven ranges (7, 7, 7, 4)
+    x = torch.randn((R, 1, 1, Cin), device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn((Cout, 1, 1, Cin), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn((Cout,), device="cuda", generator=g)
+    res = torch.randn((R, 1, 1, Cout), device="cuda", generator=g).to(torch.bfloat16)
+    ref = (x.float().view(R, Cin) @ w.float().view(Cout, Cin).t() + b + res.float().view(R, Cout)).clamp_min(0)
+    base = dense.conv2d_forward(x, w, b, res, 1, 0, True).float().view(R, Cout)
+    for ks in (2, 4, 25):
+        y = dense.conv2d_forward_splitk(x, w, b, res, True, ks).float().view(R, Cout)
+        y2 = dense.conv2d_forward_splitk(x, w, b, res, True, ks).float().view(R, Cout)
+        assert torch.equal(y, y2)                                            # deterministic fold
+        scale = ref.abs().max().item()
+        assert (y - ref).abs().max().item() <= 2.0 ** -7 * scale            # one bf16 rounding of the result
+        assert (y - base).abs().max().item() <= 2.0 ** -7 * scale
+    assert torch.equal(dense.conv2d_forward_splitk(x, w, b, res, True, 1).float().view(R, Cout), base)
