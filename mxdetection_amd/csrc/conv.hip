@@ -47,6 +47,8 @@ struct ConvP {
   int ksplit;      // > 1 (static 1x1 path only): the grid is ksplit x tiles, split ks multiplies channel slices
                    // [ks * per, (ks + 1) * per) and writes raw fp32 sums to partial[ks][M][Ncols]
   float* partial;
+  const void* pf;  // prefetch hint (mxdet_conv_desc_t.prefetch): read, never used
+  long long pf_bytes;
   int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
 };
 
@@ -124,6 +126,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 
   // XCD-aware tile order: blocks that share an XCD (bid % 8) walk consecutive tiles, and consecutive
   // tiles share their A rows (n fastest), so the A tile is re-read from that XCD's L2.
+  const int pf_bid = bid, pf_nwg = nwg;            // as launched: the prefetch hint's slices are dealt by this index
   int ks = 0, sl_begin = 0, sl_end = p.C >> 6;     // split-K (static 1x1 path): this workgroup's range of channel slices
   int nwg_ = nwg;
   if constexpr (TAPS == 1) {
@@ -711,6 +714,17 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   __syncthreads();
   MXDET_CS(4);
 
+  // ---- next layer's filter: every workgroup touches a slice while its epilogue runs (the loads are consumed only at the
+  // very end; they are older than the epilogue's own operand loads, whose wait therefore covers them) ----
+  uint4 pfv[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  if (p.pf != nullptr) {
+    const long long pf_stride = (long long)pf_nwg * NTHR * 16;       // (workgroup index inside this launch / grouped item)
+    long long off = ((long long)pf_bid * NTHR + tid) * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k, off += pf_stride)
+      if (off + 16 <= p.pf_bytes) pfv[k] = *(const uint4*)((const char*)p.pf + off);
+  }
+
   // ---- epilogue ---------------------------------------------------------------------------------
   float* ep = (float*)smem_raw + wid * 32 * EP_STRIDE;
   constexpr int LPR = WTN / 8;          // lanes per row on read-back
@@ -823,6 +837,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
     }
   }
+  if (p.pf != nullptr) asm volatile("" ::"v"(pfv[0].x), "v"(pfv[1].x), "v"(pfv[2].x), "v"(pfv[3].x));
 #ifdef MXDET_CONV_STAMP
   if (cs_on) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1413,6 +1428,7 @@ extern "C" int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, c
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.relu = d->relu; p.res_up = d->res_upsample;
   p.M = d->N * d->Ho * d->Wo;
+  p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
   return launch<false>(p, as_stream(stream));
 }
 
@@ -1516,6 +1532,7 @@ extern "C" int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.relu = 0; p.res_up = 0;
   p.M = d->N * d->H * d->W;
+  p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
   return launch<true>(p, as_stream(stream));
 }
 
@@ -1577,6 +1594,7 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
       p.M = d->N * d->H * d->W;
     }
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
     {
       const int tc = (d->stride != 1 && (kind == 1 || d->KH * d->KW == 1)) ? 0
                      : (d->KH == 1 && d->KW == 1 && d->pad == 0) ? 1 : (d->KH == 3 && d->KW == 3 && d->pad == 1) ? 2 : 0;

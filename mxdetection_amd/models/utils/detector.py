@@ -558,9 +558,35 @@ class DetectorBase:
     def train_step(self, image, gt_boxes, im_info, step=0, image_offset=0, lr=0.0025, gt_masks=None,
                    momentum=0.9, wd=1e-4):
         self._upd, self._upd_done = ((lr, momentum, wd) if self.dist is None else None), []
+        from ...ops import dense
+        trace = not getattr(self, "_pf_wired", False) and os.environ.get("MXDET_TUNE_PREFETCH", "1") != "0"
+        if trace:
+            dense.PF_TRACE = []
         try:
             losses = self.forward_backward(image, gt_boxes, im_info, step, image_offset, gt_masks=gt_masks)
         finally:
             self._upd = None
+            if trace:
+                self._wire_prefetch(dense.PF_TRACE)
+                dense.PF_TRACE = None
         self.optimizer_step(lr, momentum, wd)
         return losses
+
+    def _wire_prefetch(self, trace):
+        """Prefetch hints from the issue order of the first eager step: every single convolution launch names the filter
+        the NEXT convolution launch (single or grouped, forward or data gradient) reads, so that it is warm in the
+        Infinity Cache when that launch starts (mxdet_conv_desc_t.prefetch; +2 % on the step for the backbone chain
+        alone). A layer launched more than once per direction (heads shared across pyramid levels) keeps its last
+        successor. The order is the host's issue order: launches of the RPN branch interleave as they were issued."""
+        from ...ops import dense
+        for (layer, kind, w, key), (_, _, nxt, _) in zip(trace[:-1], trace[1:]):
+            if nxt is None or nxt == w:          # the same filter again (a head shared across pyramid levels)
+                continue
+            if kind == "f":
+                layer.pf_fwd = nxt
+            elif kind == "b":
+                layer.pf_bwd = nxt
+            elif key is not None and os.environ.get("MXDET_TUNE_PREFETCH", "1") != "2":
+                dense.GROUP_HINTS[key] = nxt     # grouped launch: its table is rebuilt with the hint at the next eager call
+                dense._group_plans.pop(key, None)
+        self._pf_wired = True

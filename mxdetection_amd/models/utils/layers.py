@@ -218,6 +218,9 @@ class ConvLayer:
             self.bias_f32 = self.frozen_bias
         self.wt = None
         self.device = device
+        # filters to warm while this layer's forward / data gradient runs (the layer executed next); see
+        # mxdet_conv_desc_t.prefetch and ResNet.wire_prefetch
+        self.pf_fwd = self.pf_bwd = None
 
     # called after arena.finalize()
     def materialize(self):
@@ -244,8 +247,10 @@ class ConvLayer:
             dense.filter_transpose(self.w_bf16, self.wt)
 
     def forward(self, x, relu=False, residual=None, res_upsample=False, out=None):
+        if dense.PF_TRACE is not None:
+            dense.PF_TRACE.append((self, "f", dense.mem_range(self.w_bf16), None))
         return dense.conv2d_forward(x, self.w_bf16, self.bias_f32, residual, self.stride, self.pad, relu, res_upsample,
-                                    out)
+                                    out, prefetch=self.pf_fwd)
 
     def fwd_call(self, x, relu=False, residual=None, res_upsample=False, out=None):
         """Argument tuple of this layer's forward for dense.conv2d_group("fwd", ...)."""
@@ -261,8 +266,10 @@ class ConvLayer:
                 out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
             if self.ws.try_fuse(self.dgrad_call(dy, x_shape, residual, relu_mask, accumulate, out)):
                 return out
+        if dense.PF_TRACE is not None:
+            dense.PF_TRACE.append((self, "b", dense.mem_range(self.wt), None))
         return dense.conv2d_dgrad(dy, self.wt, x_shape, self.k, self.k, self.stride, self.pad, residual, relu_mask,
-                                  accumulate, out)
+                                  accumulate, out, prefetch=self.pf_bwd)
 
     def backward_weight(self, x, dy, accumulate=False):
         if self.ws.grouping and not accumulate:

@@ -11,8 +11,21 @@ from .._lib import ConvDescT, check, ptr, stream_ptr
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
-def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=False, accumulate=False):
+def mem_range(*tensors):
+    """(ptr, bytes) of one tensor, or of the span of several when they sit next to each other (the filters of a
+    bottleneck's conv1 and projection shortcut are neighbours in the bf16 arena); else of the first."""
+    spans = [(t.data_ptr(), t.numel() * t.element_size()) for t in tensors]
+    lo = min(p for p, _ in spans)
+    hi = max(p + n for p, n in spans)
+    if hi - lo <= 2 * sum(n for _, n in set(spans)):
+        return (lo, hi - lo)
+    return spans[0]
+
+
+def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=False, accumulate=False, prefetch=None):
     d = ConvDescT()
+    if prefetch is not None:      # the filter(s) of the launch that runs next (mxdet_conv_desc_t.prefetch): tensor or (ptr, bytes)
+        d.prefetch, d.prefetch_bytes = prefetch if isinstance(prefetch, tuple) else mem_range(prefetch)
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = N, H, W, Cin, Cout, KH, KW, stride, pad
     d.Ho = (H + 2 * pad - KH) // stride + 1
     d.Wo = (W + 2 * pad - KW) // stride + 1
@@ -20,11 +33,11 @@ def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=
     return d
 
 
-def conv2d_forward(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None):
+def conv2d_forward(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None, prefetch=None):
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
-    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_upsample)
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_upsample, prefetch=prefetch)
     if out is None:
         out = torch.empty((N, d.Ho, d.Wo, Cout), dtype=torch.bfloat16, device=x.device)
     check(lib.mxdet_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), stream_ptr()),
@@ -48,12 +61,14 @@ def conv2d_forward_splitk(x, w, bias=None, residual=None, relu=False, ksplit=4, 
     return out
 
 
-def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None):
+def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None,
+                 prefetch=None):
     """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter)."""
     lib = _lib.load()
     N, H, W, Cin = x_shape
     Cout = dy.shape[3]
-    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate)
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate,
+                  prefetch=prefetch)
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
     check(lib.mxdet_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(residual), ptr(relu_mask), ptr(out), stream_ptr()),
@@ -88,7 +103,8 @@ class GroupedConv:
     conv2d_dgrad (dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out); `out` is required. The
     plan holds device addresses: build it once in eager mode, relaunch while the tensors stay where they are."""
 
-    def __init__(self, kind, calls, device):
+    def __init__(self, kind, calls, device, hint=None):
+        """hint: (ptr, bytes) the launch after this one reads first; the group's first item carries it."""
         lib = _lib.load()
         n = len(calls)
         items = (_lib.ConvItemT * n)()
@@ -100,14 +116,17 @@ class GroupedConv:
                 x, w, bias, residual, stride, pad, relu, res_up, out = c
                 N, H, W, Cin = x.shape
                 Cout, KH, KW, _ = w.shape
-                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_up)
+                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_up, prefetch=hint)
+                hint = None
                 it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = dp(x), dp(w), dp(bias), dp(residual), None, dp(out)
                 self.flops += 2.0 * N * it.desc.Ho * it.desc.Wo * Cout * KH * KW * Cin
             else:
                 dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c
                 N, H, W, Cin = x_shape
                 Cout = dy.shape[3]
-                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate)
+                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate,
+                                    prefetch=hint)
+                hint = None
                 it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = dp(dy), dp(wt), None, dp(residual), dp(relu_mask), dp(out)
                 self.flops += 2.0 * N * dy.shape[1] * dy.shape[2] * Cout * KH * KW * Cin
         nbytes = lib.mxdet_conv2d_grouped_table_bytes(n)
@@ -126,16 +145,26 @@ class GroupedConv:
 _group_plans = {}
 
 
+# Issue-order trace of one eager step, for the prefetch hints (mxdet_conv_desc_t.prefetch): entries are
+# (layer or None, "f" | "b" | "g", (ptr, bytes) of the filter(s) the launch reads, plan key of a grouped launch).
+# models/utils/detector.py wires every launch's hint to the filters of the launch that follows it; a grouped launch's
+# hint lives in GROUP_HINTS (its plan is rebuilt with it at the next eager call).
+PF_TRACE = None
+GROUP_HINTS = {}
+
+
 def conv2d_group(kind, calls, device):
     """Run `calls` (see GroupedConv) as one grouped launch; plans are cached by the tensors' addresses. Under stream
     capture an unseen group cannot upload its table: it falls back to one launch per call (same results)."""
+    key = (kind,) + tuple(tuple(t.data_ptr() if torch.is_tensor(t) else t for t in c) for c in calls)
+    if PF_TRACE is not None and calls:
+        PF_TRACE.append((None, "g", mem_range(*[c[1] for c in calls]), key if len(calls) > 1 else None))
     if len(calls) == 1:
         plan = None
     else:
-        key = (kind,) + tuple(tuple(t.data_ptr() if torch.is_tensor(t) else t for t in c) for c in calls)
         plan = _group_plans.get(key)
         if plan is None and not torch.cuda.is_current_stream_capturing():
-            plan = GroupedConv(kind, calls, device)
+            plan = GroupedConv(kind, calls, device, GROUP_HINTS.get(key))
             _group_plans[key] = plan
     if plan is not None:
         plan.launch()
