@@ -84,17 +84,17 @@ class ConvTimer:
         def s_wgrad(x, dy, KH, KW, *a, **kw):
             return "N=%d %dx%d %d->%d %dx%d" % (x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.shape[3], KH, KW)
 
-        def f_fwd(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None):
+        def f_fwd(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None, **_):
             N, H, W, Cin = x.shape
             Cout, KH, KW, _ = w.shape
             Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
             return 2.0 * N * Ho * Wo * Cout * KH * KW * Cin
 
-        def f_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None):
+        def f_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None, **_):
             N, Ho, Wo, Cout = dy.shape
             return 2.0 * N * Ho * Wo * Cout * KH * KW * x_shape[3]
 
-        def f_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=False, workspace=None):
+        def f_wgrad(x, dy, KH, KW, stride=1, pad=0, dw=None, db=None, accumulate=False, workspace=None, **_):
             N, Ho, Wo, Cout = dy.shape
             return 2.0 * N * Ho * Wo * Cout * KH * KW * x.shape[3]
 
