@@ -427,6 +427,7 @@ def main():
                        "wgrad_side_stream": not args.no_wgrad_stream,
                        "rpn_branch_stream": not args.no_branch_stream,
                        "grouped_wgrad": not args.no_grouped_wgrad,
+                       "filter_prefetch_hints": os.environ.get("MXDET_TUNE_PREFETCH", "1") != "0",
                        "params_trainable": model.num_params()},
             "model_mfma_roofline_frac": (round(per_gpu * TRAIN_CONV_FLOP_PER_IMAGE / MFMA_PEAK_BF16, 4)
                                          if args.model == "faster_rcnn" else None),
