@@ -418,7 +418,7 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
 // s; v_readlane hands them out as scalars). Fixed summation order (roi ascending, row bins, column bins): bit-
 // reproducible. The sums differ from the oracle's sample-by-sample order in the last bits (tolerance in the test).
 constexpr int kSegW = 8;          // pixels per wave
-constexpr int kSegWaves = 8;      // waves (segment columns) per workgroup
+constexpr int kSegWaves = 4;      // waves (segment columns) per workgroup
 constexpr int kSegChunk = 1024;   // rois per list round
 
 struct RoiSegGrid {
