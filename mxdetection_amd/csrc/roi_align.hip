@@ -407,7 +407,7 @@ roi_align_bwd_gather_kernel(FeatPyr f, RoiRows rr, int C, const RoiTab* __restri
 
 // ---- backward, segment form (default) ----------------------------------------------------------------------------------
 // Two launches: a per-roi box pass (R threads) and the gather. A gather workgroup owns a tile of `rows_per_wg` pyramid
-// rows x up to 8 consecutive 8-pixel segments (one WAVE per segment column; a lane owns 4 channels, 8 x 4 fp32 sums in
+// rows x up to kSegWaves (4) consecutive 8-pixel segments (one WAVE per segment column; a lane owns 4 channels, 8 x 4 fp32 sums in
 // registers per row). It first builds, in LDS and in ascending roi order, the list of rois whose valid samples touch its
 // tile (one coalesced 32-B record per roi), then every wave walks the list once per row of the tile. Per (roi, row,
 // segment) hit the bilinear weights are collapsed per pooling bin -- they are separable:
