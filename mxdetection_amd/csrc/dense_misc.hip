@@ -264,7 +264,7 @@ stem_pool_kernel(const T* __restrict__ img, int N, int H, int W, int Ho, int Wo,
         for (int r = 0; r < 2; ++r) pmax[q][i][j][r] = (u16x2_t){0, 0};
   // tiles that touch no border of the stem map need no per-value validity select (wave-uniform test)
   const bool interior = cr0 >= 0 && cr0 + 5 <= Ho && cc0 >= 0 && cc0 + 128 <= Wo;
-#pragma unroll
+#pragma unroll 1
   for (int cr = 0; cr < 5; ++cr) {
     f32x4_t acc[4][2];
 #pragma unroll
