@@ -325,6 +325,12 @@ typedef struct {
    * 32.7 us with a cold filter, 24.0 us with a warm one). The contents are never used. */
   const void* prefetch;
   int64_t prefetch_bytes;
+  /* Optional 1-bit ReLU mask, byte [pixel][channel / 8], bit k = (value of channel 8 j + k) > 0 (the channel count must
+   * be a multiple of 8). fwd: if non-null the kernel ALSO writes the mask of the values it stores (the activation's
+   * ReLU mask for the backward pass, 1/16 of its bytes). dgrad with relu = 1: if non-null it is read INSTEAD of the
+   * 16-bit relu_mask operand (which may then be null) -- same result, 1/16 of the operand traffic: the expand-layer
+   * data gradients are HBM-bound and their mask is a forward activation that is cold in every cache. */
+  void* relu_bits;
 } mxdet_conv_desc_t;
 
 int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w,

@@ -53,7 +53,7 @@ class ConvDescT(C.Structure):
         ("stride", c_i32), ("pad", c_i32),
         ("Ho", c_i32), ("Wo", c_i32),
         ("relu", c_i32), ("res_upsample", c_i32), ("accumulate", c_i32),
-        ("prefetch", c_vp), ("prefetch_bytes", c_i64),
+        ("prefetch", c_vp), ("prefetch_bytes", c_i64), ("relu_bits", c_vp),
     ]
 
 

@@ -49,6 +49,10 @@ struct ConvP {
   float* partial;
   const void* pf;  // prefetch hint (mxdet_conv_desc_t.prefetch): read, never used
   long long pf_bytes;
+  // 1-bit ReLU masks (mxdet_conv_desc_t.relu_bits): byte [pixel][col / 8], bit k = (value of column col + k) > 0.
+  // forward: written next to y; data gradient: read instead of the 16-bit mask operand
+  unsigned char* bits_out;
+  const unsigned char* bits_in;
   int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
 };
 
@@ -784,6 +788,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       for (int ps = 0; ps < PASSES; ++ps)
         rmsk[ps] = *(const uint4*)(p.mask + pixs[ps] * p.Ncols + (oks[ps] ? col : 0));
     }
+    unsigned rbits[PASSES];
+    if (p.bits_in) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps)
+        rbits[ps] = p.bits_in[(pixs[ps] * p.Ncols + (oks[ps] ? col : 0)) >> 3];
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -825,7 +835,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
           if (!(hi != 0u && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
         }
       }
-      if (p.relu && !p.mask) {
+      if (p.bits_in) {
+        const unsigned mb = rbits[ps];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (!((mb >> k) & 1u)) v[k] = 0.0f;
+      }
+      if (p.relu && !p.mask && !p.bits_in) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
       }
@@ -835,6 +851,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       o.z = pack_bf16x2(v[4], v[5]);
       o.w = pack_bf16x2(v[6], v[7]);
       if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
+      if (p.bits_out && oks[ps]) {
+        // the mask of the STORED values: bf16 > 0 <=> sign clear and magnitude non-zero (as the 16-bit mask test reads it)
+        const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+        unsigned mb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned lo = w4[k] & 0xffffu, hi = w4[k] >> 16;
+          mb |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * k);
+          mb |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * k + 1);
+        }
+        p.bits_out[(pixs[ps] * p.Ncols + col) >> 3] = (unsigned char)mb;
+      }
     }
   }
   if (p.pf != nullptr) asm volatile("" ::"v"(pfv[0].x), "v"(pfv[1].x), "v"(pfv[2].x), "v"(pfv[3].x));
@@ -1429,6 +1457,8 @@ extern "C" int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, c
   p.relu = d->relu; p.res_up = d->res_upsample;
   p.M = d->N * d->Ho * d->Wo;
   p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
+  p.bits_out = (unsigned char*)d->relu_bits;
+  MXDET_REQUIRE(!d->relu_bits || d->Cout % 8 == 0, MXDET_ESHAPE, "conv2d_fwd: relu_bits needs Cout %% 8 == 0");
   return launch<false>(p, as_stream(stream));
 }
 
@@ -1525,8 +1555,9 @@ extern "C" int mxdet_conv2d_dgrad(const mxdet_conv_desc_t* d, const uint16_t* dy
   memset(&p, 0, sizeof(p));
   p.x = dy; p.w = wt; p.bias = nullptr; p.y = dx;
   p.res = residual ? residual : (d->accumulate ? dx : nullptr);
-  p.mask = d->relu ? relu_mask : nullptr;
-  MXDET_REQUIRE(!d->relu || relu_mask, MXDET_EINVAL, "conv2d_dgrad: relu set without relu_mask");
+  p.mask = (d->relu && !d->relu_bits) ? relu_mask : nullptr;
+  p.bits_in = d->relu ? (const unsigned char*)d->relu_bits : nullptr;
+  MXDET_REQUIRE(!d->relu || relu_mask || d->relu_bits, MXDET_EINVAL, "conv2d_dgrad: relu set without relu_mask / relu_bits");
   p.N = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.C = d->Cout;
   p.Hd = d->H; p.Wd = d->W; p.Ncols = d->Cin;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
@@ -1576,6 +1607,7 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
       MXDET_REQUIRE(d->Cin % 64 == 0 && d->Cout % 8 == 0, MXDET_ESHAPE, "conv2d_grouped_plan: item %d: Cin %% 64, Cout %% 8", i);
       p.x = (const uint16_t*)items[i].src; p.w = (const uint16_t*)items[i].filt; p.bias = items[i].bias;
       p.res = (const uint16_t*)items[i].residual; p.mask = nullptr; p.y = (uint16_t*)items[i].dst;
+      p.bits_out = (unsigned char*)d->relu_bits;
       p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.C = d->Cin;
       p.Hd = d->Ho; p.Wd = d->Wo; p.Ncols = d->Cout;
       p.relu = d->relu; p.res_up = d->res_upsample;
@@ -1583,11 +1615,12 @@ extern "C" int mxdet_conv2d_grouped_plan(const mxdet_conv_item_t* items, int32_t
     } else {
       MXDET_REQUIRE(d->Cout % 64 == 0 && d->Cin % 8 == 0, MXDET_ESHAPE, "conv2d_grouped_plan: item %d: Cout %% 64, Cin %% 8", i);
       MXDET_REQUIRE(d->stride == 1, MXDET_ESHAPE, "conv2d_grouped_plan: item %d: strided data gradients are not grouped", i);
-      MXDET_REQUIRE(!d->relu || items[i].relu_mask, MXDET_EINVAL, "conv2d_grouped_plan: item %d: relu without mask", i);
+      MXDET_REQUIRE(!d->relu || items[i].relu_mask || d->relu_bits, MXDET_EINVAL, "conv2d_grouped_plan: item %d: relu without mask", i);
       p.x = (const uint16_t*)items[i].src; p.w = (const uint16_t*)items[i].filt; p.bias = nullptr;
       p.y = (uint16_t*)items[i].dst;
       p.res = items[i].residual ? (const uint16_t*)items[i].residual : (d->accumulate ? (const uint16_t*)items[i].dst : nullptr);
-      p.mask = d->relu ? (const uint16_t*)items[i].relu_mask : nullptr;
+      p.mask = (d->relu && !d->relu_bits) ? (const uint16_t*)items[i].relu_mask : nullptr;
+      p.bits_in = d->relu ? (const unsigned char*)d->relu_bits : nullptr;
       p.N = d->N; p.Hs = d->Ho; p.Ws = d->Wo; p.C = d->Cout;
       p.Hd = d->H; p.Wd = d->W; p.Ncols = d->Cin;
       p.relu = 0; p.res_up = 0;

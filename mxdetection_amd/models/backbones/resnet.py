@@ -6,10 +6,15 @@ BatchNorm(use_global_stats=True), Activation, Pooling, elemwise_add (README.md:3
 conv is ONE kernel with the BN shift, the residual add and the ReLU fused into its epilogue, and every
 backward ReLU / shortcut add is fused into a dgrad epilogue.
 """
+import os
+
 import torch
 
 from ...ops import dense
 from ..utils.layers import ConvLayer, cached_buf
+
+
+BITMASKS = os.environ.get("MXDET_TUNE_RELU_BITS", "1") == "1"      # 1-bit ReLU masks for the backbone's data gradients
 
 
 class Bottleneck:
@@ -42,21 +47,32 @@ class Bottleneck:
             self.down.plan(x_shape)
         return self.conv3.out_shape(s2)
 
-    def forward(self, x):
-        self.x = x
+    def _bits(self, key, shape):
+        return cached_buf(self.bufs, key, shape[:3] + (shape[3] // 8,), torch.uint8, self.conv1.device)
+
+    def forward(self, x, x_bits=None):
+        """x_bits: the 1-bit ReLU mask of x (the producer's `bits_out`), or None. Trainable blocks have every convolution
+        write the 1-bit mask of its activation next to it: the data gradients read those instead of the activations (a
+        forward activation is cold in every cache by the time backward needs it, and the expand-layer data gradients
+        are HBM-bound: the mask was a third of their traffic)."""
+        self.x, self.x_bits = x, x_bits
+        bits = self.trainable and BITMASKS
         a1 = self._buf("a1", self.conv1.out_shape(x.shape))
         s2 = self.conv2.out_shape(a1.shape)
         oshape = self.conv3.out_shape(s2)
+        self.a1_bits = self._bits("a1b", a1.shape) if bits else None
+        self.a2_bits = self._bits("a2b", s2) if bits else None
+        self.y_bits = self._bits("yb", oshape) if bits else None
         if self.down is None:
-            self.a1 = self.conv1.forward(x, relu=True, out=a1)
+            self.a1 = self.conv1.forward(x, relu=True, out=a1, bits_out=self.a1_bits)
             sc = x
         else:       # conv1 and the projection shortcut read the same x: one grouped launch
             sc = self._buf("sc", oshape)
-            dense.conv2d_group("fwd", [self.conv1.fwd_call(x, relu=True, out=a1), self.down.fwd_call(x, out=sc)],
-                               self.conv1.device)
+            dense.conv2d_group("fwd", [self.conv1.fwd_call(x, relu=True, out=a1, bits_out=self.a1_bits),
+                                       self.down.fwd_call(x, out=sc)], self.conv1.device)
             self.a1 = a1
-        self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", s2))
-        self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape))
+        self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", s2), bits_out=self.a2_bits)
+        self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape), bits_out=self.y_bits)
         return self.y
 
     def backward(self, ds, dx_buf, dx_has_grad):
@@ -67,23 +83,26 @@ class Bottleneck:
         """
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
         c3.backward_weight(self.a2, ds)
-        d_a2 = c3.backward_data(ds, self.a2.shape, relu_mask=self.a2, out=self._buf("d_a2", self.a2.shape))
+        d_a2 = c3.backward_data(ds, self.a2.shape, relu_mask=self.a2, out=self._buf("d_a2", self.a2.shape),
+                                relu_bits=self.a2_bits)
         c2.backward_weight(self.a1, d_a2)
-        d_a1 = c2.backward_data(d_a2, self.a1.shape, relu_mask=self.a1, out=self._buf("d_a1", self.a1.shape))
+        d_a1 = c2.backward_data(d_a2, self.a1.shape, relu_mask=self.a1, out=self._buf("d_a1", self.a1.shape),
+                                relu_bits=self.a1_bits)
         c1.backward_weight(self.x, d_a1)
         if self.down is not None:
             self.down.backward_weight(self.x, ds)
         if not self.need_dx:
             return None
+        xb = self.x_bits
         if self.down is not None:
             self.down.backward_data(ds, self.x.shape, accumulate=dx_has_grad, out=dx_buf)
-            c1.backward_data(d_a1, self.x.shape, residual=dx_buf, relu_mask=self.x, out=dx_buf)
+            c1.backward_data(d_a1, self.x.shape, residual=dx_buf, relu_mask=self.x, out=dx_buf, relu_bits=xb)
         else:
             if dx_has_grad:
                 dense.add_bf16(dx_buf, ds, dx_buf)
-                c1.backward_data(d_a1, self.x.shape, residual=dx_buf, relu_mask=self.x, out=dx_buf)
+                c1.backward_data(d_a1, self.x.shape, residual=dx_buf, relu_mask=self.x, out=dx_buf, relu_bits=xb)
             else:
-                c1.backward_data(d_a1, self.x.shape, residual=ds, relu_mask=self.x, out=dx_buf)
+                c1.backward_data(d_a1, self.x.shape, residual=ds, relu_mask=self.x, out=dx_buf, relu_bits=xb)
         return dx_buf
 
 
@@ -135,9 +154,11 @@ class ResNet:
                                     cached_buf(self.bufs, "pool", (N, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1, 64),
                                                torch.bfloat16, dev))
         outs = []
+        xb = None                       # 1-bit ReLU mask of x, when its producer is a trainable block
         for st in self.stages:
             for b in st:
-                x = b.forward(x)
+                x = b.forward(x, xb)
+                xb = b.y_bits
             outs.append(x)
         self.outs = outs
         return outs

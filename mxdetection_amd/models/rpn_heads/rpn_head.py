@@ -5,6 +5,8 @@ Plugin slot: models/rpn_heads (/root/reference/README.md:28) with ops (README.md
 (README.md:16,19). Everything (targets, sampling, NMS) stays on the GPU; MXNet-lineage code runs these as
 numpy/Cython CustomOps on the host.
 """
+import os
+
 import torch
 
 from ...core import anchor as A_
@@ -14,6 +16,9 @@ from ...ops.proposal import PyramidProposal
 from ..utils.layers import ConvLayer, cached_buf
 
 HEAD_CPAD = 64   # fused cls+reg output channels padded so that dgrad's reduction dim is a multiple of 64
+
+
+RELU_BITS = os.environ.get("MXDET_TUNE_RELU_BITS", "1") == "1"
 
 
 class RPNHead:
@@ -67,8 +72,12 @@ class RPNHead:
         self.P = P
         tb = [self._buf("t%d" % l, p.shape) for l, p in enumerate(P)]
         hb = [self._buf("h%d" % l, p.shape[:3] + (HEAD_CPAD,)) for l, p in enumerate(P)]
-        self.conv.forward(P[0], relu=True, out=tb[0])
-        dense.conv2d_group("fwd", [self.conv.fwd_call(P[l], relu=True, out=tb[l]) for l in range(1, len(P))], self.device)
+        # 1-bit ReLU masks of the conv activations for the head's data gradient (the P2-level activation is 68.8 MB)
+        self.tbits = [self._buf("tb%d" % l, p.shape[:3] + (p.shape[3] // 8,), dtype=torch.uint8) if RELU_BITS else None
+                      for l, p in enumerate(P)]
+        self.conv.forward(P[0], relu=True, out=tb[0], bits_out=self.tbits[0])
+        dense.conv2d_group("fwd", [self.conv.fwd_call(P[l], relu=True, out=tb[l], bits_out=self.tbits[l])
+                                   for l in range(1, len(P))], self.device)
         self.out.forward(tb[0], out=hb[0])
         dense.conv2d_group("fwd", [self.out.fwd_call(tb[l], out=hb[l]) for l in range(1, len(P))], self.device)
         self.t, self.h = tb, hb
@@ -112,8 +121,9 @@ class RPNHead:
         grouped = self.out.ws.grouping     # grouped form: the plan sums the levels of a shared filter itself
         for l in range(L):
             self.out.backward_weight(self.t[l], self.gh[l], accumulate=(l > 0) and not grouped)
-        self.out.backward_data(self.gh[0], self.t[0].shape, relu_mask=self.t[0], out=dt[0])
-        dense.conv2d_group("dgrad", [self.out.dgrad_call(self.gh[l], self.t[l].shape, relu_mask=self.t[l], out=dt[l])
+        self.out.backward_data(self.gh[0], self.t[0].shape, relu_mask=self.t[0], out=dt[0], relu_bits=self.tbits[0])
+        dense.conv2d_group("dgrad", [self.out.dgrad_call(self.gh[l], self.t[l].shape, relu_mask=self.t[l], out=dt[l],
+                                                         relu_bits=self.tbits[l])
                                      for l in range(1, L)], self.device)
         for l in range(L):
             self.conv.backward_weight(self.P[l], dt[l], accumulate=(l > 0) and not grouped)

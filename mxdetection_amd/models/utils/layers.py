@@ -246,21 +246,25 @@ class ConvLayer:
         if self.trainable:
             dense.filter_transpose(self.w_bf16, self.wt)
 
-    def forward(self, x, relu=False, residual=None, res_upsample=False, out=None):
+    def forward(self, x, relu=False, residual=None, res_upsample=False, out=None, bits_out=None):
+        """bits_out: uint8 [N,Ho,Wo,Cout/8] receiving the 1-bit ReLU mask of the output (for the backward pass)."""
         if dense.PF_TRACE is not None:
             dense.PF_TRACE.append((self, "f", dense.mem_range(self.w_bf16), None))
         return dense.conv2d_forward(x, self.w_bf16, self.bias_f32, residual, self.stride, self.pad, relu, res_upsample,
-                                    out, prefetch=self.pf_fwd)
+                                    out, prefetch=self.pf_fwd, bits_out=bits_out)
 
-    def fwd_call(self, x, relu=False, residual=None, res_upsample=False, out=None):
+    def fwd_call(self, x, relu=False, residual=None, res_upsample=False, out=None, bits_out=None):
         """Argument tuple of this layer's forward for dense.conv2d_group("fwd", ...)."""
-        return (x, self.w_bf16, self.bias_f32, residual, self.stride, self.pad, relu, res_upsample, out)
+        t = (x, self.w_bf16, self.bias_f32, residual, self.stride, self.pad, relu, res_upsample, out)
+        return t if bits_out is None else t + (bits_out,)
 
-    def dgrad_call(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None):
+    def dgrad_call(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None, relu_bits=None):
         """Argument tuple of this layer's data gradient for dense.conv2d_group("dgrad", ...)."""
-        return (dy, self.wt, tuple(x_shape), self.k, self.k, self.stride, self.pad, residual, relu_mask, accumulate, out)
+        t = (dy, self.wt, tuple(x_shape), self.k, self.k, self.stride, self.pad, residual, relu_mask, accumulate, out)
+        return t if relu_bits is None else t + (relu_bits,)
 
-    def backward_data(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None):
+    def backward_data(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None, relu_bits=None):
+        """relu_bits: the 1-bit form of relu_mask (read instead of it: 1/16 of the operand bytes)."""
         if self.ws is not None and self.ws.fusing and self.stride == 1 and self.trainable:
             if out is None:
                 out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
@@ -268,8 +272,9 @@ class ConvLayer:
                 return out
         if dense.PF_TRACE is not None:
             dense.PF_TRACE.append((self, "b", dense.mem_range(self.wt), None))
-        return dense.conv2d_dgrad(dy, self.wt, x_shape, self.k, self.k, self.stride, self.pad, residual, relu_mask,
-                                  accumulate, out, prefetch=self.pf_bwd)
+        return dense.conv2d_dgrad(dy, self.wt, x_shape, self.k, self.k, self.stride, self.pad, residual,
+                                  None if relu_bits is not None else relu_mask, accumulate, out, prefetch=self.pf_bwd,
+                                  relu_bits=relu_bits)
 
     def backward_weight(self, x, dy, accumulate=False):
         if self.ws.grouping and not accumulate:

@@ -22,8 +22,11 @@ def mem_range(*tensors):
     return spans[0]
 
 
-def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=False, accumulate=False, prefetch=None):
+def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=False, accumulate=False, prefetch=None,
+              relu_bits=None):
     d = ConvDescT()
+    if relu_bits is not None:     # 1-bit ReLU mask (mxdet_conv_desc_t.relu_bits): uint8 [N,H,W,C/8]
+        d.relu_bits = relu_bits.data_ptr()
     if prefetch is not None:      # the filter(s) of the launch that runs next (mxdet_conv_desc_t.prefetch): tensor or (ptr, bytes)
         d.prefetch, d.prefetch_bytes = prefetch if isinstance(prefetch, tuple) else mem_range(prefetch)
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = N, H, W, Cin, Cout, KH, KW, stride, pad
@@ -33,11 +36,13 @@ def conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=False, res_upsample=
     return d
 
 
-def conv2d_forward(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None, prefetch=None):
+def conv2d_forward(x, w, bias=None, residual=None, stride=1, pad=0, relu=False, res_upsample=False, out=None, prefetch=None,
+                   bits_out=None):
+    """bits_out: uint8 [N,Ho,Wo,Cout/8] that receives the 1-bit (value > 0) mask of the output."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
-    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_upsample, prefetch=prefetch)
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_upsample, prefetch=prefetch, relu_bits=bits_out)
     if out is None:
         out = torch.empty((N, d.Ho, d.Wo, Cout), dtype=torch.bfloat16, device=x.device)
     check(lib.mxdet_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), stream_ptr()),
@@ -62,13 +67,14 @@ def conv2d_forward_splitk(x, w, bias=None, residual=None, relu=False, ksplit=4, 
 
 
 def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None,
-                 prefetch=None):
-    """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter)."""
+                 prefetch=None, relu_bits=None):
+    """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter). relu_bits: the 1-bit form of relu_mask
+    (uint8 [N,H,W,Cin/8], written by conv2d_forward(bits_out=...)); if given it is read instead of relu_mask."""
     lib = _lib.load()
     N, H, W, Cin = x_shape
     Cout = dy.shape[3]
-    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate,
-                  prefetch=prefetch)
+    d = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=(relu_mask is not None or relu_bits is not None),
+                  accumulate=accumulate, prefetch=prefetch, relu_bits=relu_bits)
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
     check(lib.mxdet_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(residual), ptr(relu_mask), ptr(out), stream_ptr()),
@@ -113,21 +119,24 @@ class GroupedConv:
         dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
         for it, c in zip(items, calls):
             if self.kind == 0:
-                x, w, bias, residual, stride, pad, relu, res_up, out = c
+                x, w, bias, residual, stride, pad, relu, res_up, out = c[:9]
+                bits = c[9] if len(c) > 9 else None
                 N, H, W, Cin = x.shape
                 Cout, KH, KW, _ = w.shape
-                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_up, prefetch=hint)
+                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu, res_up, prefetch=hint, relu_bits=bits)
                 hint = None
                 it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = dp(x), dp(w), dp(bias), dp(residual), None, dp(out)
                 self.flops += 2.0 * N * it.desc.Ho * it.desc.Wo * Cout * KH * KW * Cin
             else:
-                dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c
+                dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c[:11]
+                bits = c[11] if len(c) > 11 else None            # 1-bit form of relu_mask, read instead of it
                 N, H, W, Cin = x_shape
                 Cout = dy.shape[3]
-                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=relu_mask is not None, accumulate=accumulate,
-                                    prefetch=hint)
+                it.desc = conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad, relu=(relu_mask is not None or bits is not None),
+                                    accumulate=accumulate, prefetch=hint, relu_bits=bits)
                 hint = None
-                it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = dp(dy), dp(wt), None, dp(residual), dp(relu_mask), dp(out)
+                it.src, it.filt, it.bias, it.residual, it.relu_mask, it.dst = (dp(dy), dp(wt), None, dp(residual),
+                                                                              None if bits is not None else dp(relu_mask), dp(out))
                 self.flops += 2.0 * N * dy.shape[1] * dy.shape[2] * Cout * KH * KW * Cin
         nbytes = lib.mxdet_conv2d_grouped_table_bytes(n)
         host = (C.c_ubyte * nbytes)()
@@ -171,11 +180,12 @@ def conv2d_group(kind, calls, device):
         return
     for c in calls:
         if kind == "fwd":
-            x, w, bias, residual, stride, pad, relu, res_up, out = c
-            conv2d_forward(x, w, bias, residual, stride, pad, relu, res_up, out)
+            x, w, bias, residual, stride, pad, relu, res_up, out = c[:9]
+            conv2d_forward(x, w, bias, residual, stride, pad, relu, res_up, out, bits_out=c[9] if len(c) > 9 else None)
         else:
-            dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c
-            conv2d_dgrad(dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out)
+            dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out = c[:11]
+            conv2d_dgrad(dy, wt, x_shape, KH, KW, stride, pad, residual, relu_mask, accumulate, out,
+                         relu_bits=c[11] if len(c) > 11 else None)
 
 
 def fused_dgrad(call, device, wplan, w_begin, w_end, wbuf):

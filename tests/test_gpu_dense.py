@@ -487,3 +487,35 @@ def test_conv_fwd_splitk_vs_torch(hip):
         assert (y - ref).abs().max().item() <= 2.0 ** -7 * scale            # one bf16 rounding of the result
         assert (y - base).abs().max().item() <= 2.0 ** -7 * scale
     assert torch.equal(dense.conv2d_forward_splitk(x, w, b, res, True, 1).float().view(R, Cout), base)
+
+
+def test_relu_bitmask_forward_and_dgrad(hip):
+    """1-bit ReLU masks (mxdet_conv_desc_t.relu_bits): the forward kernel writes bit k of byte [pixel][c / 8] = (stored
+    value of channel c + k) > 0; a data gradient reading that mask is bit-identical to one reading the activation."""
+    import torch
+    from mxdetection_amd.ops import dense
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (N, H, W, Cin, Cout, K, s) in [(2, 50, 84, 256, 1024, 1, 1), (2, 25, 42, 128, 128, 3, 1), (1, 40, 52, 64, 192, 3, 2)]:
+        pad = K // 2
+        x = torch.randn((N, H, W, Cin), device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn((Cout, K, K, Cin), device="cuda", generator=g) * (1.0 / (K * K * Cin) ** 0.5)).to(torch.bfloat16)
+        b = torch.randn((Cout,), device="cuda", generator=g) * 0.1
+        Ho, Wo = (H + 2 * pad - K) // s + 1, (W + 2 * pad - K) // s + 1
+        bits = torch.full((N, Ho, Wo, Cout // 8), 0xAA, dtype=torch.uint8, device="cuda")
+        y = dense.conv2d_forward(x, w, b, None, s, pad, True, bits_out=bits)
+        y0 = dense.conv2d_forward(x, w, b, None, s, pad, True)
+        assert torch.equal(y, y0)                                      # the mask output changes nothing else
+        want = (y.view(N, Ho, Wo, Cout // 8, 8) > 0).to(torch.int32)
+        want = (want * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+        assert torch.equal(bits, want)
+        assert 0.2 < (y > 0).float().mean().item() < 0.8
+        # a data gradient INTO this activation (a layer that consumes y), masked by y > 0
+        Cn = 128
+        w2 = (torch.randn((Cn, 1, 1, Cout), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        dy = torch.randn((N, Ho, Wo, Cn), device="cuda", generator=g).to(torch.bfloat16)
+        res = torch.randn((N, Ho, Wo, Cout), device="cuda", generator=g).to(torch.bfloat16)
+        wt2 = dense.filter_transpose(w2)
+        d_mask = dense.conv2d_dgrad(dy, wt2, tuple(y.shape), 1, 1, 1, 0, residual=res, relu_mask=y)
+        d_bits = dense.conv2d_dgrad(dy, wt2, tuple(y.shape), 1, 1, 1, 0, residual=res, relu_bits=bits)
+        assert torch.equal(d_mask, d_bits)
+        assert torch.all(d_bits[y <= 0] == 0)
