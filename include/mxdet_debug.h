@@ -41,7 +41,9 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_ROI_TABLE 12   /* RoIAlign backward (gather): 1 = the three-kernel table form instead of the segment form */
 #define MXDET_TUNE_ROI_ROWS 13    /* RoIAlign backward, segment form: rows per tile on maps with >= 64 rows (default 2) */
 #define MXDET_TUNE_STATIC_TAPS 14 /* conv: 1 = stride-1 1x1 / 3x3 layers use the unrolled static-tap K loop (default 1) */
-#define MXDET_TUNE_COUNT 15
+#define MXDET_TUNE_T128W 15     /* conv: stride-1 1x1 / 3x3 layers of >= 128 columns use 128x128 tiles of eight waves from this many
+                                    128x128 tiles on (default 1000000 = never; measured in profiles/r02_d_static_cfg_sweep.txt) */
+#define MXDET_TUNE_COUNT 16
 int mxdet_debug_set_tuning(int32_t which, int64_t value);
 
 #ifdef __cplusplus

@@ -171,7 +171,8 @@ SIGNATURES = {
 DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
                  "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
 TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "WGB_ENABLE": 6,
-               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14}
+               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14,
+               "T128W": 15}
 
 _lib = None
 

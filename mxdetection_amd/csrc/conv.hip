@@ -205,7 +205,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2);
 #pragma unroll
     for (int i = 0; i < GB; ++i)
-#ifndef MXDET_ABL_NOLOAD
+#if !defined(MXDET_ABL_NOLOAD) && !defined(MXDET_ABL_NOBLOAD)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 128 + (wid * GB + i) * 1024), 16,
                                                (int)(2u * (unsigned)wrow[i]), so_b, 0, 0);
 #else
@@ -538,7 +538,16 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   for (int s0 = 0; s0 < NS - 1; ++s0)
     issue_a(s0, s0 % TAPS, (sl_begin + s0 / TAPS) * 64, s0 < (sl_end - sl_begin) * TAPS);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * GA) : "memory");
+#ifdef MXDET_ABL_NOBFRAG
+  bf16x8_t bf0[NT], bf1[NT];     // ablation: the filter fragments are read once (stale LDS contents) and kept
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { bf0[j] = *(const bf16x8_t*)(fb0 + j * 1024); bf1[j] = *(const bf16x8_t*)(fb1 + j * 1024); }
+#endif
+#ifdef MXDET_ABL_NOKLOOP
+  for (int cs = sl_begin; cs < sl_begin; cs += SL) {
+#else
   for (int cs = sl_begin; cs < nslices; cs += SL) {
+#endif
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       if (SL > 1 && cs + sl >= nslices) break;                        // wave-uniform
@@ -551,15 +560,23 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         asm volatile("" ::: "memory");
         // all fragment reads of the step first (immediate offsets), then the next stage's loads, then the MFMAs behind
         // counted lgkmcnt waits: one exposed LDS latency per step, underneath the DMA issue
+#ifdef MXDET_ABL_NOBFRAG
+        bf16x8_t af0[MT], af1[MT];
+#else
         bf16x8_t af0[MT], bf0[NT], af1[MT], bf1[NT];
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) af0[i] = *(const bf16x8_t*)(fa0 + cur * STAGE + i * 1024);
+#ifndef MXDET_ABL_NOBFRAG
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf0[j] = *(const bf16x8_t*)(fb0 + cur * STAGE + j * 1024);
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) af1[i] = *(const bf16x8_t*)(fa1 + cur * STAGE + i * 1024);
+#ifndef MXDET_ABL_NOBFRAG
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf1[j] = *(const bf16x8_t*)(fb1 + cur * STAGE + j * 1024);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         {
           const int ahead = tp + NS - 1;
@@ -569,6 +586,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+#ifndef MXDET_ABL_NOMFMA
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -579,6 +597,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { asm volatile("" ::"v"(af0[i])); asm volatile("" ::"v"(af1[i])); }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { asm volatile("" ::"v"(bf0[j])); asm volatile("" ::"v"(bf1[j])); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
       }
@@ -1342,6 +1366,10 @@ static int launch(ConvP& p, hipStream_t s) {
     case 43: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 9>(p, s);
     case 44: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 9>(p, s);
     case 45: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
+    case 46: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 1, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 1, 2, DGRAD, false, 1, 9>(p, s);
+    case 47: if (p.KH * p.KW == 1) return launch_cfg<256, 64, 4, 1, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<256, 64, 4, 1, 2, DGRAD, false, 1, 9>(p, s);
+    case 48: if (p.KH * p.KW == 1) return launch_cfg<256, 128, 4, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<256, 128, 4, 2, 2, DGRAD, false, 1, 9>(p, s);
+    case 49: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 4, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 4, 2, DGRAD, false, 1, 9>(p, s);
     case 50: if (tr_ok(p)) return launch_tr<128, 64, 4, 1, DGRAD>(p, s); break;   // other layers: the heuristic
     case 51: if (tr_ok(p)) return launch_tr<64, 64, 2, 2, DGRAD>(p, s); break;
     case 52: if (tr_ok(p)) return launch_tr<128, 64, 4, 2, DGRAD>(p, s); break;   // 8 waves, 32 x 32 per wave
@@ -1404,6 +1432,9 @@ static int launch(ConvP& p, hipStream_t s) {
       default: return MXDET_LAUNCH_ST(128, 128, 2, 2, 2);
     }
   }
+  // many rows, short reduction: 128 x 128 tiles of eight waves (64 x 32 per wave) -- half the LDS-DMA bytes per MFMA of
+  // the 64 x 128 tile (the small tiles' K loop is bound by what a CU's vector-memory path takes in, ~64 B/clk)
+  if (st != 0 && p.Ncols >= 128 && t128 >= tuning(MXDET_TUNE_T128W)) return MXDET_LAUNCH_ST(128, 128, 2, 4, 2);
   if (t64 >= thr_t64()) return MXDET_LAUNCH_ST(64, 128, 2, 2, 2);
   return MXDET_LAUNCH_ST(64, 64, 2, 2, 3);
 #undef MXDET_LAUNCH_ST

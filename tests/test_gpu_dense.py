@@ -489,6 +489,37 @@ def test_conv_fwd_splitk_vs_torch(hip):
     assert torch.equal(dense.conv2d_forward_splitk(x, w, b, res, True, 1).float().view(R, Cout), base)
 
 
+def test_conv_eight_wave_tile_route_bit_identical(hip):
+    """MXDET_TUNE_T128W routes stride-1 1x1 / 3x3 layers to 128x128 tiles of eight waves: the reduction order of an output
+    element (channel slices, taps inside a slice, two 32-deep halves) does not depend on the tile, so forward and data
+    gradient must equal the default route bit for bit."""
+    import torch
+    from mxdetection_amd import _lib
+    from mxdetection_amd.ops import dense
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (H, W, Cin, Cout, K) in ((40, 52, 64, 256, 1), (24, 40, 128, 128, 3)):
+        pad = K // 2
+        x = torch.randn((2, H, W, Cin), device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn((Cout, K, K, Cin), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((Cout,), device="cuda", generator=g)
+        res = torch.randn((2, H, W, Cout), device="cuda", generator=g).to(torch.bfloat16)
+        dy = torch.randn((2, H, W, Cout), device="cuda", generator=g).to(torch.bfloat16)
+        wt = dense.filter_transpose(w)
+        y0 = dense.conv2d_forward(x, w, b, res, 1, pad, True).clone()
+        dx0 = dense.conv2d_dgrad(dy, wt, tuple(x.shape), K, K, 1, pad, relu_mask=x).clone()
+        lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T128W"], 1)
+        try:
+            y1 = dense.conv2d_forward(x, w, b, res, 1, pad, True).clone()
+            dx1 = dense.conv2d_dgrad(dy, wt, tuple(x.shape), K, K, 1, pad, relu_mask=x).clone()
+        finally:
+            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T128W"], -1)
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, 1, pad)
+        ref = (ref.permute(0, 2, 3, 1) + res.float()).clamp_min(0)
+        assert (y1.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+
+
 def test_relu_bitmask_forward_and_dgrad(hip):
     """1-bit ReLU masks (mxdet_conv_desc_t.relu_bits): the forward kernel writes bit k of byte [pixel][c / 8] = (stored
     value of channel c + k) > 0; a data gradient reading that mask is bit-identical to one reading the activation."""

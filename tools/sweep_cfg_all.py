@@ -7,7 +7,8 @@ import torch
 from mxdetection_amd import _lib
 from mxdetection_amd.ops import dense
 lib = _lib.load()
-CFGS = [5, 6, 7, 8, 12, 14, 20, 21, 22, 23]
+CFGS = [int(c) for c in os.environ.get("SWEEP_CFGS", "5,6,7,8,12,14,20,21,22,23").split(",")]
+STATIC_ONLY = any(40 <= c < 50 for c in CFGS)     # cfgs 40-49 assume a stride-1 1x1 / 3x3 layer
 # (H, W, Cin, Cout, k, stride) at N = 2
 SHAPES = [(200, 336, 64, 64, 1, 1), (200, 336, 64, 64, 3, 1), (200, 336, 64, 256, 1, 1), (200, 336, 256, 64, 1, 1),
           (200, 336, 256, 128, 1, 1), (200, 336, 128, 128, 3, 2), (100, 168, 128, 512, 1, 1), (100, 168, 512, 128, 1, 1),
@@ -45,6 +46,8 @@ for (H, W, Cin, Cout, K, s) in SHAPES:
     for kind in ("fwd", "dgrad"):
         if kind == "dgrad" and (Cout % 64 or s == 2):
             continue          # stride-2 dgrad has its own (parity) path
+        if STATIC_ONLY and s != 1:
+            continue
         fn = (lambda: dense.conv2d_forward(x, w, bias, None, s, p, True, False, y)) if kind == "fwd" else \
              (lambda: dense.conv2d_dgrad(dy, wt, tuple(x.shape), K, K, s, p, relu_mask=x, out=dx))
         lib.mxdet_debug_force_conv_cfg(0)
