@@ -1370,6 +1370,12 @@ static int launch(ConvP& p, hipStream_t s) {
     case 47: if (p.KH * p.KW == 1) return launch_cfg<256, 64, 4, 1, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<256, 64, 4, 1, 2, DGRAD, false, 1, 9>(p, s);
     case 48: if (p.KH * p.KW == 1) return launch_cfg<256, 128, 4, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<256, 128, 4, 2, 2, DGRAD, false, 1, 9>(p, s);
     case 49: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 4, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 4, 2, DGRAD, false, 1, 9>(p, s);
+    case 60: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 2, 3, DGRAD, false, 1, 9>(p, s);
+    case 61: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 2, 4, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 2, 4, DGRAD, false, 1, 9>(p, s);
+    case 62: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 4, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 4, 3, DGRAD, false, 1, 9>(p, s);
+    case 63: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 4, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 4, 3, DGRAD, false, 1, 9>(p, s);
+    case 64: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 6, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 6, DGRAD, false, 1, 9>(p, s);
+    case 65: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 2, 2, DGRAD, false, 1, 9>(p, s);
     case 50: if (tr_ok(p)) return launch_tr<128, 64, 4, 1, DGRAD>(p, s); break;   // other layers: the heuristic
     case 51: if (tr_ok(p)) return launch_tr<64, 64, 2, 2, DGRAD>(p, s); break;
     case 52: if (tr_ok(p)) return launch_tr<128, 64, 4, 2, DGRAD>(p, s); break;   // 8 waves, 32 x 32 per wave

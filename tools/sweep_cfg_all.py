@@ -8,7 +8,7 @@ from mxdetection_amd import _lib
 from mxdetection_amd.ops import dense
 lib = _lib.load()
 CFGS = [int(c) for c in os.environ.get("SWEEP_CFGS", "5,6,7,8,12,14,20,21,22,23").split(",")]
-STATIC_ONLY = any(40 <= c < 50 for c in CFGS)     # cfgs 40-49 assume a stride-1 1x1 / 3x3 layer
+STATIC_ONLY = any(40 <= c < 50 or 60 <= c < 70 for c in CFGS)     # cfgs 40-49 assume a stride-1 1x1 / 3x3 layer
 # (H, W, Cin, Cout, k, stride) at N = 2
 SHAPES = [(200, 336, 64, 64, 1, 1), (200, 336, 64, 64, 3, 1), (200, 336, 64, 256, 1, 1), (200, 336, 256, 64, 1, 1),
           (200, 336, 256, 128, 1, 1), (200, 336, 128, 128, 3, 2), (100, 168, 128, 512, 1, 1), (100, 168, 512, 128, 1, 1),
@@ -34,6 +34,8 @@ def timeit(fn, reps=12):
 torch.manual_seed(0)
 tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0]}
 for (H, W, Cin, Cout, K, s) in SHAPES:
+    if os.environ.get("SWEEP_MAXH") and H > int(os.environ["SWEEP_MAXH"]):
+        continue
     p = K // 2
     x = torch.randn(2, H, W, Cin, device="cuda").to(torch.bfloat16)
     w = (torch.randn(Cout, K, K, Cin, device="cuda") * 0.05).to(torch.bfloat16)
