@@ -98,7 +98,16 @@ class ConvTimer:
             N, Ho, Wo, Cout = dy.shape
             return 2.0 * N * Ho * Wo * Cout * KH * KW * x.shape[3]
 
+        def f_chain(x, w, bias, w2, *a, **kw):       # 3x3 (Cin -> 64) + 1x1 (64 -> 256) in one launch
+            N, H, W, Cin = x.shape
+            return 2.0 * N * H * W * (w.shape[0] * 9 * Cin + w2.shape[0] * w.shape[0])
+
+        def s_chain(x, w, bias, w2, *a, **kw):
+            return "N=%d %dx%d %d->%d 3x3 + ->%d 1x1 (chained)" % (x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0],
+                                                                   w2.shape[0])
+
         wrap("conv2d_forward", "conv_igemm_fwd", f_fwd, s_fwd)
+        wrap("conv2d_forward_chain", "conv_igemm_fwd", f_chain, s_chain)
         wrap("conv2d_dgrad", "conv_igemm_dgrad", f_dgrad, s_dgrad)
         wrap("conv2d_wgrad", "conv_wgrad", f_wgrad, s_wgrad)
         # grouped weight gradients (one launch pair per parameter bucket) are launches of the same family

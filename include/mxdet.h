@@ -336,6 +336,15 @@ typedef struct {
 int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w,
                      const float* bias, const uint16_t* residual, uint16_t* y,
                      mxdet_stream_t stream);
+/* Chained forward: y2 = act2( act( conv3x3(x, w) + bias ) (*) w2 + bias2 + residual2 ), act = ReLU if d->relu, act2 = ReLU if
+ * relu2 -- the tail of a bottleneck block (conv2 -> conv3 + shortcut) whose intermediate map nobody needs afterwards, i.e.
+ * a FROZEN block (models/backbones, /root/reference/README.md:27: ResNet stage C2 with frozen_stages = 1). d describes the
+ * 3x3 (stride 1, pad 1, Cin % 64 == 0, Cout == 64); w2 is [cout2][1][1][64] with cout2 == 256; residual2 / y2 are
+ * [N, Ho, Wo, cout2]. One launch, the 64-channel intermediate never reaches memory; bit-identical to mxdet_conv2d_fwd
+ * twice. d->prefetch is honoured; d->relu_bits and d->res_upsample must be unset. */
+int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
+                           const uint16_t* w2, const float* bias2, int32_t cout2, int32_t relu2,
+                           const uint16_t* residual2, uint16_t* y2, mxdet_stream_t stream);
 /* Forward with the reduction split over `ksplit` ranges of 64-channel slices, for 1x1 / stride-1 layers with a long
  * reduction on few rows (fully connected layers on pooled rois): raw fp32 tiles in the caller's workspace, folded in
  * split order (deterministic) with bias / residual / ReLU by a second kernel. Last-bit different from mxdet_conv2d_fwd

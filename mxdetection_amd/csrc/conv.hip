@@ -54,6 +54,12 @@ struct ConvP {
   unsigned char* bits_out;
   const unsigned char* bits_in;
   int force_cfg;   // 0 = heuristic; 1..4 = a specific tile configuration (tuning / tests)
+  // chained 1x1 (CHAIN template parameter: mxdet_conv2d_fwd_chain): y2 = relu?(relu(conv3x3(x) + bias) * w2 + bias2 + res2)
+  const uint16_t* chain_w;     // [CHAIN][Ncols] (Ncols == BN == 64: a wave holds every mid channel of its rows)
+  const float* chain_bias;     // [CHAIN] or null
+  const uint16_t* chain_res;   // [M][CHAIN] or null
+  uint16_t* chain_y;           // [M][CHAIN]
+  int chain_relu;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -88,7 +94,8 @@ __device__ unsigned long long g_conv_stamp[2][8];
 // displacement and filter column are loop-invariant scalars, and the ~50 dependent scalar instructions per step that
 // walked (kh, kw, channel slice) at run time disappear -- on the 64-row tiles, at 1-3 waves per SIMD, that serial
 // bookkeeping cost as many cycles per step as the step's eight MFMAs.
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, bool EXT_LDS = false, int KU = 1, int TAPS = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, bool EXT_LDS = false, int KU = 1, int TAPS = 0,
+          int CHAIN = 0>
 __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg,
                                                 unsigned char* lds_pool = nullptr) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -109,7 +116,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   constexpr int EP_STRIDE = WTN + 4;
   constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
   constexpr int MAIN_BYTES = NBUF * STAGE * 2;
-  constexpr int SMEM_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
+  // CHAIN > 0: a 1x1 convolution to CHAIN columns follows in the same workgroup (see after the K loop); its whole filter
+  // (CHAIN x 64 bf16) sits behind the ring / epilogue area for the workgroup's life
+  static_assert(CHAIN == 0 || (TAPS == 9 && !DGRAD && WN == 1 && BN == 64 && CHAIN % (8 * NW) == 0 && !EXT_LDS),
+                "chain: forward 3x3 whose waves own all 64 mid channels of their rows");
+  constexpr int CHAIN_OFF = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
+  constexpr int SMEM_BYTES = CHAIN_OFF + CHAIN * 128;
   unsigned char* smem_raw;
   if constexpr (EXT_LDS) {
     smem_raw = lds_pool;
@@ -216,6 +228,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
       issue_b(s0, s0 % TAPS, (sl_begin + s0 / TAPS) * 64, s0 < (sl_end - sl_begin) * TAPS);
+  }
+  if constexpr (CHAIN > 0) {
+    // the chained filter: CHAIN rows x 64 channels in the B-stage image (8 rows per piece), older than every ring piece of
+    // this wave, so the K loop's first counted wait covers it
+    const __amdgpu_buffer_rsrc_t rsrc_c = make_rsrc(p.chain_w, 2u * (unsigned)CHAIN * 64u);
+#pragma unroll
+    for (int i = 0; i < CHAIN / 8 / NW; ++i) {
+      const int r = (wid * (CHAIN / 8 / NW) + i) * 8 + lrow;
+      const unsigned vo = 2u * (unsigned)(r * 64 + ((lslot ^ ((r >> 1) & 7)) << 3));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lptr_t)(smem_raw + CHAIN_OFF + (wid * (CHAIN / 8 / NW) + i) * 1024), 16,
+                                               (int)vo, 0, 0, 0);
+    }
   }
   int a_off[GA];
   unsigned a_mask[GA];
@@ -759,14 +783,80 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   constexpr int RPP = 64 / LPR;         // rows per pass
   constexpr int PASSES = 32 / RPP;
   const int rl = lane / LPR, cg = lane - rl * LPR;
+  // CHAIN: the tile just computed (BM rows x 64 mid channels) is the A operand of a 1x1 convolution to CHAIN columns. A wave
+  // owns all 64 channels of its rows (WN == 1), so nothing crosses waves: accumulators -> wave-private fp32 staging ->
+  // rows read back in the A-fragment layout, + bias, ReLU, rounded to bf16 exactly as the unfused layer stores them; then
+  // per 64-column chunk 2 * MT * NT MFMAs against the filter image in LDS (two 32-deep halves in the order of the
+  // stand-alone 1x1 kernel: bit-identical sums) and the ordinary epilogue on the chunk.
+  bf16x8_t af2[CHAIN > 0 ? MT : 1][2];
+  if constexpr (CHAIN > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(i * 16 + fq * 4 + r) * EP_STRIDE + j * 16 + frow] = acc[i][j][r];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+      if (p.bias) {
+        c0 = *(const float4*)(p.bias + hf * 32 + fq * 8);
+        c1 = *(const float4*)(p.bias + hf * 32 + fq * 8 + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float4 v0 = *(const float4*)(ep + (i * 16 + frow) * EP_STRIDE + hf * 32 + fq * 8);
+        const float4 v1 = *(const float4*)(ep + (i * 16 + frow) * EP_STRIDE + hf * 32 + fq * 8 + 4);
+        float v[8] = {v0.x + c0.x, v0.y + c0.y, v0.z + c0.z, v0.w + c0.w, v1.x + c1.x, v1.y + c1.y, v1.z + c1.z, v1.w + c1.w};
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]);
+        o.w = pack_bf16x2(v[6], v[7]);
+        af2[i][hf] = __builtin_bit_cast(bf16x8_t, o);
+      }
+    }
+  }
+  // epilogue operands: the layer's own, or the chained convolution's
+  const int e_ncols = CHAIN > 0 ? CHAIN : p.Ncols;
+  const float* const e_bias = CHAIN > 0 ? p.chain_bias : p.bias;
+  const uint16_t* const e_res = CHAIN > 0 ? p.chain_res : p.res;
+  uint16_t* const e_y = CHAIN > 0 ? p.chain_y : p.y;
+  const int e_relu = CHAIN > 0 ? p.chain_relu : p.relu;
+#pragma unroll 1      // (unrolled: no faster; the filter fragments straight from L2 instead of LDS, 48 KiB per workgroup: no faster)
+  for (int chunk = 0; chunk < (CHAIN > 0 ? CHAIN / BN : 1); ++chunk) {
+  const int n0c = CHAIN > 0 ? chunk * BN : n0;
+  if constexpr (CHAIN > 0) {
+    const uint16_t* wl = (const uint16_t*)(smem_raw + CHAIN_OFF);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      bf16x8_t bw[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bw[j] = *(const bf16x8_t*)(wl + lds_off(n0c + j * 16 + frow, hf * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[i][hf], bw[j], acc[i][j], 0, 0, 0);
+    }
+  }
   // bias: one pair of loads per lane for the whole epilogue (the column does not depend on the pass)
-  const int col = n0 + wn * WTN + cg * 8;
-  const bool colok = col < p.Ncols;
+  const int col = n0c + wn * WTN + cg * 8;
+  const bool colok = col < e_ncols;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-  if (p.bias) {
+  if (e_bias) {
     const int cb = colok ? col : 0;
-    b0 = *(const float4*)(p.bias + cb);
-    b1 = *(const float4*)(p.bias + cb + 4);
+    b0 = *(const float4*)(e_bias + cb);
+    b1 = *(const float4*)(e_bias + cb + 4);
   }
 #pragma unroll
   for (int h = 0; h < MT / 2; ++h) {
@@ -792,31 +882,31 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       oks[ps] = rowok && colok;
       pixs[ps] = oks[ps] ? pix : 0;
     }
-    if (p.res) {
+    if (e_res) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
-        size_t ri = pixs[ps] * p.Ncols + (oks[ps] ? col : 0);
-        if (p.res_up) {
+        size_t ri = pixs[ps] * e_ncols + (oks[ps] ? col : 0);
+        if (CHAIN == 0 && p.res_up) {
           const int m = (int)pixs[ps];
           int img = m / (p.Hd * p.Wd);
           int rem = m - img * (p.Hd * p.Wd);
           int hd = rem / p.Wd, wd = rem - hd * p.Wd;
           int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
-          ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * p.Ncols + (oks[ps] ? col : 0);
+          ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * e_ncols + (oks[ps] ? col : 0);
         }
-        rres[ps] = *(const uint4*)(p.res + ri);
+        rres[ps] = *(const uint4*)(e_res + ri);
       }
     }
-    if (p.mask) {
+    if (CHAIN == 0 && p.mask) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps)
-        rmsk[ps] = *(const uint4*)(p.mask + pixs[ps] * p.Ncols + (oks[ps] ? col : 0));
+        rmsk[ps] = *(const uint4*)(p.mask + pixs[ps] * e_ncols + (oks[ps] ? col : 0));
     }
     unsigned rbits[PASSES];
-    if (p.bits_in) {
+    if (CHAIN == 0 && p.bits_in) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps)
-        rbits[ps] = p.bits_in[(pixs[ps] * p.Ncols + (oks[ps] ? col : 0)) >> 3];
+        rbits[ps] = p.bits_in[(pixs[ps] * e_ncols + (oks[ps] ? col : 0)) >> 3];
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -834,7 +924,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       if constexpr (TAPS == 1) {
         if (p.ksplit > 1) {                          // split-K: raw sums; bias / residual / ReLU happen in the fold kernel
           if (oks[ps]) {
-            float* dst = p.partial + ((size_t)ks * p.M + pixs[ps]) * p.Ncols + col;
+            float* dst = p.partial + ((size_t)ks * p.M + pixs[ps]) * e_ncols + col;
             *(float4*)dst = v0;
             *(float4*)(dst + 4) = v1;
           }
@@ -842,14 +932,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         }
       }
       float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
-      if (p.res) {
+      if (e_res) {
         const uint4 rv = rres[ps];
         v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
         v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
         v[4] += __uint_as_float(rv.z << 16); v[5] += __uint_as_float(rv.z & 0xffff0000u);
         v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
       }
-      if (p.mask) {
+      if (CHAIN == 0 && p.mask) {
         // bf16 > 0  <=>  sign clear and magnitude non-zero
         const unsigned mm[4] = {rmsk[ps].x, rmsk[ps].y, rmsk[ps].z, rmsk[ps].w};
 #pragma unroll
@@ -859,13 +949,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
           if (!(hi != 0u && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
         }
       }
-      if (p.bits_in) {
+      if (CHAIN == 0 && p.bits_in) {
         const unsigned mb = rbits[ps];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (!((mb >> k) & 1u)) v[k] = 0.0f;
       }
-      if (p.relu && !p.mask && !p.bits_in) {
+      if (e_relu && (CHAIN > 0 || (!p.mask && !p.bits_in))) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
       }
@@ -874,8 +964,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       o.y = pack_bf16x2(v[2], v[3]);
       o.z = pack_bf16x2(v[4], v[5]);
       o.w = pack_bf16x2(v[6], v[7]);
-      if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
-      if (p.bits_out && oks[ps]) {
+      if (oks[ps]) *(uint4*)(e_y + pixs[ps] * e_ncols + col) = o;
+      if (CHAIN == 0 && p.bits_out && oks[ps]) {
         // the mask of the STORED values: bf16 > 0 <=> sign clear and magnitude non-zero (as the 16-bit mask test reads it)
         const unsigned w4[4] = {o.x, o.y, o.z, o.w};
         unsigned mb = 0;
@@ -885,10 +975,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
           mb |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * k);
           mb |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * k + 1);
         }
-        p.bits_out[(pixs[ps] * p.Ncols + col) >> 3] = (unsigned char)mb;
+        p.bits_out[(pixs[ps] * e_ncols + col) >> 3] = (unsigned char)mb;
       }
     }
   }
+  }   // chunk
   if (p.pf != nullptr) asm volatile("" ::"v"(pfv[0].x), "v"(pfv[1].x), "v"(pfv[2].x), "v"(pfv[3].x));
 #ifdef MXDET_CONV_STAMP
   if (cs_on) {
@@ -1218,10 +1309,10 @@ static int launch_tr(ConvP& p, hipStream_t s) {
   return check_launch("conv2d");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0, int CHAIN = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
-  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR, false, KU, TAPS>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR, false, KU, TAPS, CHAIN>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped form: independent convolutions that share one tile configuration (the 3x3 of every pyramid level of an RPN
@@ -1299,7 +1390,7 @@ static int thr_t64() { return (int)tuning(MXDET_TUNE_T64); }
 static int thr_t128() { return (int)tuning(MXDET_TUNE_T128); }
 static int thr_par64() { return (int)tuning(MXDET_TUNE_PAR64); }
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0, int CHAIN = 0>
 static int launch_cfg(ConvP& p, hipStream_t s) {
   if (PAR) {   // rows grouped by parity class: tiles never straddle two classes
     int t = 0;
@@ -1314,8 +1405,8 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
   if (TAPS == 1 && p.ksplit > 1) nwg *= p.ksplit;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, KU, TAPS>), dim3((unsigned)nwg), dim3(64 * WM * WN),
-                     0, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, KU, TAPS, CHAIN>), dim3((unsigned)nwg),
+                     dim3(64 * WM * WN), 0, s, p);
   return check_launch("conv2d");
 }
 
@@ -1497,6 +1588,38 @@ extern "C" int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, c
   p.bits_out = (unsigned char*)d->relu_bits;
   MXDET_REQUIRE(!d->relu_bits || d->Cout % 8 == 0, MXDET_ESHAPE, "conv2d_fwd: relu_bits needs Cout %% 8 == 0");
   return launch<false>(p, as_stream(stream));
+}
+
+// ---- chained 3x3 -> 1x1 forward (the tail of a frozen C2 bottleneck: conv2 + ReLU, conv3 + shortcut + ReLU) --------------
+// One launch: the 3x3's 128-row x 64-channel tile never leaves the workgroup (accumulators -> bf16 A fragments, rounded as the
+// unfused layer would store them), the 1x1's 256 x 64 filter sits in LDS, and the 1x1's epilogue (bias, residual, ReLU)
+// writes the block output. Saves the intermediate map's write and read and one launch; results are bit-identical to the
+// two launches (same reduction order in both convolutions).
+extern "C" int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
+                                      const uint16_t* w2, const float* bias2, int32_t cout2, int32_t relu2,
+                                      const uint16_t* residual2, uint16_t* y2, mxdet_stream_t stream) {
+  clear_error();
+  int rc = validate(d, "conv2d_fwd_chain");
+  if (rc) return rc;
+  MXDET_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, MXDET_ESHAPE,
+                "conv2d_fwd_chain: the first convolution must be 3x3, stride 1, pad 1");
+  MXDET_REQUIRE(d->Cin % 64 == 0 && d->Cout == 64 && cout2 == 256, MXDET_ESHAPE,
+                "conv2d_fwd_chain: Cin %d must be a multiple of 64, Cout %d must be 64 and cout2 %d must be 256", d->Cin,
+                d->Cout, cout2);
+  MXDET_REQUIRE(!d->res_upsample && !d->relu_bits, MXDET_EINVAL, "conv2d_fwd_chain: no upsampled residual / relu_bits");
+  MXDET_REQUIRE(x && w && w2 && y2, MXDET_EINVAL, "conv2d_fwd_chain: null pointer");
+  MXDET_REQUIRE((long long)d->N * d->Ho * d->Wo * cout2 < (1ll << 31), MXDET_ESHAPE, "conv2d_fwd_chain: output exceeds 2^31");
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w; p.bias = bias; p.y = nullptr;
+  p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.C = d->Cin;
+  p.Hd = d->Ho; p.Wd = d->Wo; p.Ncols = d->Cout;
+  p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1;
+  p.relu = d->relu;
+  p.M = d->N * d->Ho * d->Wo;
+  p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
+  p.chain_w = w2; p.chain_bias = bias2; p.chain_res = residual2; p.chain_y = y2; p.chain_relu = relu2;
+  return launch_cfg<128, 64, 4, 1, 2, false, false, 1, 9, 256>(p, as_stream(stream));
 }
 
 // ---- split-K forward for long reductions on few rows (FC6: 1,024 rois x 12,544 features x 1,024 outputs) ----------------

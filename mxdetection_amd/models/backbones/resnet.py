@@ -15,6 +15,8 @@ from ..utils.layers import ConvLayer, cached_buf
 
 
 BITMASKS = os.environ.get("MXDET_TUNE_RELU_BITS", "1") == "1"      # 1-bit ReLU masks for the backbone's data gradients
+# frozen bottlenecks with 64 mid channels (C2): conv2 -> conv3 as one chained launch (MXDET_TUNE_CHAIN=0: two launches)
+CHAIN_FROZEN = os.environ.get("MXDET_TUNE_CHAIN", "1") != "0"
 
 
 class Bottleneck:
@@ -71,6 +73,17 @@ class Bottleneck:
             dense.conv2d_group("fwd", [self.conv1.fwd_call(x, relu=True, out=a1, bits_out=self.a1_bits),
                                        self.down.fwd_call(x, out=sc)], self.conv1.device)
             self.a1 = a1
+        if (CHAIN_FROZEN and not self.trainable and self.conv2.stride == 1 and self.conv2.cout == 64 and
+                self.conv3.cout == 256):
+            # frozen block (C2): nobody reads a2 again -- conv2 and conv3 as ONE launch, the 64-channel map stays in the
+            # workgroup (mxdet_conv2d_fwd_chain; bit-identical to the two launches)
+            if dense.PF_TRACE is not None:
+                dense.PF_TRACE.append((self.conv2, "f", dense.mem_range(self.conv3.w_bf16, self.conv2.w_bf16), None))
+            self.a2 = None
+            self.y = dense.conv2d_forward_chain(self.a1, self.conv2.w_bf16, self.conv2.bias_f32, self.conv3.w_bf16,
+                                                self.conv3.bias_f32, sc, relu=True, relu2=True,
+                                                out=self._buf("y", oshape), prefetch=self.conv2.pf_fwd)
+            return self.y
         self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", s2), bits_out=self.a2_bits)
         self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape), bits_out=self.y_bits)
         return self.y

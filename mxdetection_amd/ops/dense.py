@@ -66,6 +66,20 @@ def conv2d_forward_splitk(x, w, bias=None, residual=None, relu=False, ksplit=4, 
     return out
 
 
+def conv2d_forward_chain(x, w, bias, w2, bias2=None, residual2=None, relu=True, relu2=True, out=None, prefetch=None):
+    """3x3 (stride 1, pad 1, Cout = 64) + 1x1 (64 -> 256) in one launch: relu2?(relu?(conv(x, w) + bias) * w2 + bias2 +
+    residual2). The 64-channel intermediate map is never written (mxdet_conv2d_fwd_chain)."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cmid, Cout2 = w.shape[0], w2.shape[0]
+    d = conv_desc(N, H, W, Cin, Cmid, 3, 3, 1, 1, relu, False, prefetch=prefetch)
+    if out is None:
+        out = torch.empty((N, H, W, Cout2), dtype=torch.bfloat16, device=x.device)
+    check(lib.mxdet_conv2d_fwd_chain(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(w2), ptr(bias2), Cout2, int(relu2),
+                                     ptr(residual2), ptr(out), stream_ptr()), "conv2d_fwd_chain")
+    return out
+
+
 def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None,
                  prefetch=None, relu_bits=None):
     """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter). relu_bits: the 1-bit form of relu_mask

@@ -520,6 +520,30 @@ def test_conv_eight_wave_tile_route_bit_identical(hip):
         assert (y1.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
 
 
+def test_conv_chain_3x3_1x1_bit_identical(hip):
+    """mxdet_conv2d_fwd_chain (3x3 -> ReLU -> 1x1 + residual + ReLU in one launch, the tail of a frozen C2 bottleneck) against the
+    two launches it replaces: same bits (both convolutions keep their reduction order; the intermediate is rounded to bf16
+    exactly as the unfused layer stores it). Ragged sizes: rows not a multiple of the 128-row tile, image borders."""
+    import torch
+    from mxdetection_amd.ops import dense
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for (N, H, W, Cin, relu2, with_res, with_bias) in ((2, 37, 53, 64, True, True, True), (1, 16, 24, 128, False, False, True),
+                                                      (2, 9, 7, 64, True, True, False), (1, 200, 336, 64, True, True, True)):
+        x = torch.randn((N, H, W, Cin), device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn((64, 3, 3, Cin), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((64,), device="cuda", generator=g) if with_bias else None
+        w2 = (torch.randn((256, 1, 1, 64), device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+        b2 = torch.randn((256,), device="cuda", generator=g) if with_bias else None
+        res = torch.randn((N, H, W, 256), device="cuda", generator=g).to(torch.bfloat16) if with_res else None
+        mid = dense.conv2d_forward(x, w, b, None, 1, 1, True)
+        ref = dense.conv2d_forward(mid, w2, b2, res, 1, 0, relu2)
+        got = dense.conv2d_forward_chain(x, w, b, w2, b2, res, relu=True, relu2=relu2)
+        assert got.shape == ref.shape
+        assert torch.equal(got, ref), (N, H, W, Cin, (got.float() - ref.float()).abs().max().item())
+    with pytest.raises(Exception):
+        dense.conv2d_forward_chain(x, w, b, w2[:128].contiguous(), None, None)      # cout2 must be 256
+
+
 def test_relu_bitmask_forward_and_dgrad(hip):
     """1-bit ReLU masks (mxdet_conv_desc_t.relu_bits): the forward kernel writes bit k of byte [pixel][c / 8] = (stored
     value of channel c + k) > 0; a data gradient reading that mask is bit-identical to one reading the activation."""
