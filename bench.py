@@ -100,7 +100,9 @@ class ConvTimer:
 
         def f_chain(x, w, bias, w2, *a, **kw):       # 3x3 (Cin -> 64) + 1x1 (64 -> 256) in one launch
             N, H, W, Cin = x.shape
-            return 2.0 * N * H * W * (w.shape[0] * 9 * Cin + w2.shape[0] * w.shape[0])
+            w3 = kw.get("w3")          # (+ the next block's conv1, 256 -> 64, when it rides along)
+            return 2.0 * N * H * W * (w.shape[0] * 9 * Cin + w2.shape[0] * w.shape[0] +
+                                      (w3.shape[0] * w2.shape[0] if w3 is not None else 0))
 
         def s_chain(x, w, bias, w2, *a, **kw):
             return "N=%d %dx%d %d->%d 3x3 + ->%d 1x1 (chained)" % (x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0],

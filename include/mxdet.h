@@ -341,10 +341,14 @@ int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16
  * a FROZEN block (models/backbones, /root/reference/README.md:27: ResNet stage C2 with frozen_stages = 1). d describes the
  * 3x3 (stride 1, pad 1, Cin % 64 == 0, Cout == 64); w2 is [cout2][1][1][64] with cout2 == 256; residual2 / y2 are
  * [N, Ho, Wo, cout2]. One launch, the 64-channel intermediate never reaches memory; bit-identical to mxdet_conv2d_fwd
- * twice. d->prefetch is honoured; d->relu_bits and d->res_upsample must be unset. */
+ * twice. d->prefetch is honoured; d->relu_bits and d->res_upsample must be unset.
+ * w3 != NULL adds a third convolution in the same launch: y3 = act3( y2 (*) w3 + bias3 ), w3 [cout3][1][1][cout2] with
+ * cout3 == 64, y3 [N, Ho, Wo, cout3] -- the NEXT block's conv1, computed from the block output's stored bf16 values as
+ * they leave the workgroup (bit-identical to a further mxdet_conv2d_fwd on y2). */
 int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
                            const uint16_t* w2, const float* bias2, int32_t cout2, int32_t relu2,
-                           const uint16_t* residual2, uint16_t* y2, mxdet_stream_t stream);
+                           const uint16_t* residual2, uint16_t* y2, const uint16_t* w3, const float* bias3,
+                           int32_t cout3, int32_t relu3, uint16_t* y3, mxdet_stream_t stream);
 /* Forward with the reduction split over `ksplit` ranges of 64-channel slices, for 1x1 / stride-1 layers with a long
  * reduction on few rows (fully connected layers on pooled rois): raw fp32 tiles in the caller's workspace, folded in
  * split order (deterministic) with bias / residual / ReLU by a second kernel. Last-bit different from mxdet_conv2d_fwd

@@ -124,7 +124,8 @@ SIGNATURES = {
     "mxdet_mask_loss_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "mxdet_mask_loss": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mxdet_conv2d_fwd": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "mxdet_conv2d_fwd_chain": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "mxdet_conv2d_fwd_chain": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                       c_i32, c_vp, c_vp]),
     "mxdet_conv2d_fwd_splitk_workspace_bytes": (c_sz, [P(ConvDescT), c_i32]),
     "mxdet_conv2d_fwd_splitk": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -60,6 +60,11 @@ struct ConvP {
   const uint16_t* chain_res;   // [M][CHAIN] or null
   uint16_t* chain_y;           // [M][CHAIN]
   int chain_relu;
+  // ... and optionally a second chained 1x1 on the CHAIN-column result (the next block's conv1): y3 = relu?(y2 * w3 + bias3)
+  const uint16_t* chain3_w;    // [64][CHAIN] or null
+  const float* chain3_bias;    // [64] or null
+  uint16_t* chain3_y;          // [M][64]
+  int chain3_relu;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -823,15 +828,49 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     }
   }
   // epilogue operands: the layer's own, or the chained convolution's
-  const int e_ncols = CHAIN > 0 ? CHAIN : p.Ncols;
-  const float* const e_bias = CHAIN > 0 ? p.chain_bias : p.bias;
-  const uint16_t* const e_res = CHAIN > 0 ? p.chain_res : p.res;
-  uint16_t* const e_y = CHAIN > 0 ? p.chain_y : p.y;
-  const int e_relu = CHAIN > 0 ? p.chain_relu : p.relu;
-#pragma unroll 1      // (unrolled: no faster; the filter fragments straight from L2 instead of LDS, 48 KiB per workgroup: no faster)
-  for (int chunk = 0; chunk < (CHAIN > 0 ? CHAIN / BN : 1); ++chunk) {
-  const int n0c = CHAIN > 0 ? chunk * BN : n0;
+  // Second chained 1x1 (chain3_w != null): its 64 output columns accumulate over the chunks -- chunk c's STORED values (the
+  // bf16 words the epilogue writes) are put back into the wave's staging rows as a bf16 tile, read as A fragments and
+  // multiplied with columns [64 c, 64 c + 64) of the filter, whose fragments come straight from L2; one more trip through
+  // the loop then runs the ordinary epilogue on that accumulator (K order = chunk, half: that of the stand-alone kernel).
+  static_assert(CHAIN == 0 || MT == 2, "chain: one epilogue half covers the wave's rows");
+  constexpr int NCH = CHAIN > 0 ? CHAIN / BN : 1;
+  const bool c3 = CHAIN > 0 && p.chain3_w != nullptr;
+  f32x4_t acc3[CHAIN > 0 ? MT : 1][CHAIN > 0 ? NT : 1];
   if constexpr (CHAIN > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc3[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 1      // (unrolled: no faster; the filter fragments straight from L2 instead of LDS, 48 KiB per workgroup: no faster)
+  for (int chunk = 0; chunk < (CHAIN > 0 ? NCH + (c3 ? 1 : 0) : 1); ++chunk) {
+  const bool last3 = CHAIN > 0 && chunk == NCH;        // the trip that stores the second chained convolution
+  const int e_ncols = CHAIN > 0 ? (last3 ? BN : CHAIN) : p.Ncols;
+  const float* const e_bias = CHAIN > 0 ? (last3 ? p.chain3_bias : p.chain_bias) : p.bias;
+  const uint16_t* const e_res = CHAIN > 0 ? (last3 ? nullptr : p.chain_res) : p.res;
+  uint16_t* const e_y = CHAIN > 0 ? (last3 ? p.chain3_y : p.chain_y) : p.y;
+  const int e_relu = CHAIN > 0 ? (last3 ? p.chain3_relu : p.chain_relu) : p.relu;
+  const int n0c = CHAIN > 0 ? (last3 ? 0 : chunk * BN) : n0;
+  if constexpr (CHAIN > 0) {
+    if (last3) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = acc3[i][j];
+    }
+  }
+  // the second chained filter's fragments of this chunk: from L2, issued here so that their latency runs under the chunk
+  bf16x8_t b3[2][CHAIN > 0 ? NT : 1];
+  if constexpr (CHAIN > 0) {
+    if (c3 && !last3) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          b3[hf][j] = *(const bf16x8_t*)(p.chain3_w + (size_t)(j * 16 + frow) * CHAIN + chunk * BN + hf * 32 + fq * 8);
+    }
+  }
+  if (CHAIN > 0 && !last3) {
     const uint16_t* wl = (const uint16_t*)(smem_raw + CHAIN_OFF);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -965,6 +1004,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       o.z = pack_bf16x2(v[4], v[5]);
       o.w = pack_bf16x2(v[6], v[7]);
       if (oks[ps]) *(uint4*)(e_y + pixs[ps] * e_ncols + col) = o;
+      if constexpr (CHAIN > 0) {
+        // (this pass's fp32 rows have been read: the bf16 row takes the first 128 bytes of the same staging row)
+        if (c3 && !last3) *(uint4*)((unsigned char*)ep + row * (EP_STRIDE * 4) + ((cg ^ (row & 7)) << 4)) = o;
+      }
       if (CHAIN == 0 && p.bits_out && oks[ps]) {
         // the mask of the STORED values: bf16 > 0 <=> sign clear and magnitude non-zero (as the 16-bit mask test reads it)
         const unsigned w4[4] = {o.x, o.y, o.z, o.w};
@@ -976,6 +1019,23 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
           mb |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * k + 1);
         }
         p.bits_out[(pixs[ps] * e_ncols + col) >> 3] = (unsigned char)mb;
+      }
+    }
+  }
+  if constexpr (CHAIN > 0) {
+    if (c3 && !last3) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        bf16x8_t a3[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          a3[i] = *(const bf16x8_t*)((const unsigned char*)ep + (i * 16 + frow) * (EP_STRIDE * 4) +
+                                     (((hf * 4 + fq) ^ ((i * 16 + frow) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[i], b3[hf][j], acc3[i][j], 0, 0, 0);
       }
     }
   }
@@ -1594,10 +1654,13 @@ extern "C" int mxdet_conv2d_fwd(const mxdet_conv_desc_t* d, const uint16_t* x, c
 // One launch: the 3x3's 128-row x 64-channel tile never leaves the workgroup (accumulators -> bf16 A fragments, rounded as the
 // unfused layer would store them), the 1x1's 256 x 64 filter sits in LDS, and the 1x1's epilogue (bias, residual, ReLU)
 // writes the block output. Saves the intermediate map's write and read and one launch; results are bit-identical to the
-// two launches (same reduction order in both convolutions).
+// two launches (same reduction order in both convolutions). Optionally a THIRD convolution rides along: the next block's
+// conv1 (1x1, 256 -> 64, + bias, ReLU) accumulated over the 64-column chunks of the block output as they are stored -- the
+// block output is then not read back for it.
 extern "C" int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
                                       const uint16_t* w2, const float* bias2, int32_t cout2, int32_t relu2,
-                                      const uint16_t* residual2, uint16_t* y2, mxdet_stream_t stream) {
+                                      const uint16_t* residual2, uint16_t* y2, const uint16_t* w3, const float* bias3,
+                                      int32_t cout3, int32_t relu3, uint16_t* y3, mxdet_stream_t stream) {
   clear_error();
   int rc = validate(d, "conv2d_fwd_chain");
   if (rc) return rc;
@@ -1619,6 +1682,11 @@ extern "C" int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t
   p.M = d->N * d->Ho * d->Wo;
   p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
   p.chain_w = w2; p.chain_bias = bias2; p.chain_res = residual2; p.chain_y = y2; p.chain_relu = relu2;
+  if (w3 != nullptr) {
+    MXDET_REQUIRE(cout3 == 64 && y3 != nullptr, MXDET_ESHAPE, "conv2d_fwd_chain: the third convolution needs cout3 == 64 (got %d) and y3",
+                  cout3);
+    p.chain3_w = w3; p.chain3_bias = bias3; p.chain3_y = y3; p.chain3_relu = relu3;
+  }
   return launch_cfg<128, 64, 4, 1, 2, false, false, 1, 9, 256>(p, as_stream(stream));
 }
 

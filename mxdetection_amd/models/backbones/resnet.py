@@ -17,6 +17,8 @@ from ..utils.layers import ConvLayer, cached_buf
 BITMASKS = os.environ.get("MXDET_TUNE_RELU_BITS", "1") == "1"      # 1-bit ReLU masks for the backbone's data gradients
 # frozen bottlenecks with 64 mid channels (C2): conv2 -> conv3 as one chained launch (MXDET_TUNE_CHAIN=0: two launches)
 CHAIN_FROZEN = os.environ.get("MXDET_TUNE_CHAIN", "1") != "0"
+# ... with the NEXT block's conv1 riding along (MXDET_TUNE_CHAIN=1: conv2 -> conv3 only)
+CHAIN3_FROZEN = os.environ.get("MXDET_TUNE_CHAIN", "2") not in ("0", "1")
 
 
 class Bottleneck:
@@ -52,8 +54,16 @@ class Bottleneck:
     def _bits(self, key, shape):
         return cached_buf(self.bufs, key, shape[:3] + (shape[3] // 8,), torch.uint8, self.conv1.device)
 
-    def forward(self, x, x_bits=None):
-        """x_bits: the 1-bit ReLU mask of x (the producer's `bits_out`), or None. Trainable blocks have every convolution
+    def chainable(self):
+        """Frozen block with 64 mid channels: conv2 -> conv3 (and the next such block's conv1) run as one launch."""
+        return (CHAIN_FROZEN and not self.trainable and self.conv2.stride == 1 and self.conv2.cout == 64 and
+                self.conv3.cout == 256)
+
+    def forward(self, x, x_bits=None, a1_ready=False, next_block=None):
+        """a1_ready: this block's conv1 output was already written by the previous block's chained launch (self.a1).
+        next_block: a following chainable block without projection shortcut -- its conv1 rides along in this block's
+        chained launch.
+        x_bits: the 1-bit ReLU mask of x (the producer's `bits_out`), or None. Trainable blocks have every convolution
         write the 1-bit mask of its activation next to it: the data gradients read those instead of the activations (a
         forward activation is cold in every cache by the time backward needs it, and the expand-layer data gradients
         are HBM-bound: the mask was a third of their traffic)."""
@@ -66,23 +76,30 @@ class Bottleneck:
         self.a2_bits = self._bits("a2b", s2) if bits else None
         self.y_bits = self._bits("yb", oshape) if bits else None
         if self.down is None:
-            self.a1 = self.conv1.forward(x, relu=True, out=a1, bits_out=self.a1_bits)
+            if not a1_ready:
+                self.a1 = self.conv1.forward(x, relu=True, out=a1, bits_out=self.a1_bits)
             sc = x
         else:       # conv1 and the projection shortcut read the same x: one grouped launch
             sc = self._buf("sc", oshape)
             dense.conv2d_group("fwd", [self.conv1.fwd_call(x, relu=True, out=a1, bits_out=self.a1_bits),
                                        self.down.fwd_call(x, out=sc)], self.conv1.device)
             self.a1 = a1
-        if (CHAIN_FROZEN and not self.trainable and self.conv2.stride == 1 and self.conv2.cout == 64 and
-                self.conv3.cout == 256):
+        if self.chainable():
             # frozen block (C2): nobody reads a2 again -- conv2 and conv3 as ONE launch, the 64-channel map stays in the
-            # workgroup (mxdet_conv2d_fwd_chain; bit-identical to the two launches)
+            # workgroup (mxdet_conv2d_fwd_chain; bit-identical to the two launches); the next block's conv1 is computed
+            # from the block output as it leaves the workgroup
             if dense.PF_TRACE is not None:
                 dense.PF_TRACE.append((self.conv2, "f", dense.mem_range(self.conv3.w_bf16, self.conv2.w_bf16), None))
             self.a2 = None
-            self.y = dense.conv2d_forward_chain(self.a1, self.conv2.w_bf16, self.conv2.bias_f32, self.conv3.w_bf16,
-                                                self.conv3.bias_f32, sc, relu=True, relu2=True,
-                                                out=self._buf("y", oshape), prefetch=self.conv2.pf_fwd)
+            nb = next_block
+            kw = {}
+            if nb is not None:
+                nb.a1 = nb._buf("a1", nb.conv1.out_shape(oshape))
+                kw = dict(w3=nb.conv1.w_bf16, bias3=nb.conv1.bias_f32, relu3=True, out3=nb.a1)
+            r = dense.conv2d_forward_chain(self.a1, self.conv2.w_bf16, self.conv2.bias_f32, self.conv3.w_bf16,
+                                           self.conv3.bias_f32, sc, relu=True, relu2=True, out=self._buf("y", oshape),
+                                           prefetch=self.conv2.pf_fwd, **kw)
+            self.y = r[0] if nb is not None else r
             return self.y
         self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", s2), bits_out=self.a2_bits)
         self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape), bits_out=self.y_bits)
@@ -169,8 +186,13 @@ class ResNet:
         outs = []
         xb = None                       # 1-bit ReLU mask of x, when its producer is a trainable block
         for st in self.stages:
-            for b in st:
-                x = b.forward(x, xb)
+            ready = False
+            for i, b in enumerate(st):
+                nb = st[i + 1] if i + 1 < len(st) else None
+                ride = (CHAIN3_FROZEN and nb is not None and b.chainable() and nb.chainable() and nb.down is None and
+                        nb.conv1.cout == 64 and nb.conv1.stride == 1)
+                x = b.forward(x, xb, a1_ready=ready, next_block=nb if ride else None)
+                ready = ride
                 xb = b.y_bits
             outs.append(x)
         self.outs = outs

@@ -66,18 +66,23 @@ def conv2d_forward_splitk(x, w, bias=None, residual=None, relu=False, ksplit=4, 
     return out
 
 
-def conv2d_forward_chain(x, w, bias, w2, bias2=None, residual2=None, relu=True, relu2=True, out=None, prefetch=None):
+def conv2d_forward_chain(x, w, bias, w2, bias2=None, residual2=None, relu=True, relu2=True, out=None, prefetch=None,
+                         w3=None, bias3=None, relu3=True, out3=None):
     """3x3 (stride 1, pad 1, Cout = 64) + 1x1 (64 -> 256) in one launch: relu2?(relu?(conv(x, w) + bias) * w2 + bias2 +
-    residual2). The 64-channel intermediate map is never written (mxdet_conv2d_fwd_chain)."""
+    residual2). The 64-channel intermediate map is never written (mxdet_conv2d_fwd_chain). w3 ([64,1,1,256]): a third
+    convolution in the same launch, out3 = relu3?(out * w3 + bias3) (the next block's conv1); returns (out, out3) then."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cmid, Cout2 = w.shape[0], w2.shape[0]
     d = conv_desc(N, H, W, Cin, Cmid, 3, 3, 1, 1, relu, False, prefetch=prefetch)
     if out is None:
         out = torch.empty((N, H, W, Cout2), dtype=torch.bfloat16, device=x.device)
+    if w3 is not None and out3 is None:
+        out3 = torch.empty((N, H, W, w3.shape[0]), dtype=torch.bfloat16, device=x.device)
     check(lib.mxdet_conv2d_fwd_chain(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(w2), ptr(bias2), Cout2, int(relu2),
-                                     ptr(residual2), ptr(out), stream_ptr()), "conv2d_fwd_chain")
-    return out
+                                     ptr(residual2), ptr(out), ptr(w3), ptr(bias3), 0 if w3 is None else w3.shape[0],
+                                     int(relu3), ptr(out3), stream_ptr()), "conv2d_fwd_chain")
+    return out if w3 is None else (out, out3)
 
 
 def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None,

@@ -540,6 +540,13 @@ def test_conv_chain_3x3_1x1_bit_identical(hip):
         got = dense.conv2d_forward_chain(x, w, b, w2, b2, res, relu=True, relu2=relu2)
         assert got.shape == ref.shape
         assert torch.equal(got, ref), (N, H, W, Cin, (got.float() - ref.float()).abs().max().item())
+        # ... and with the next block's conv1 (1x1, 256 -> 64, bias, ReLU) riding along
+        w3 = (torch.randn((64, 1, 1, 256), device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+        b3 = torch.randn((64,), device="cuda", generator=g) if with_bias else None
+        ref3 = dense.conv2d_forward(ref, w3, b3, None, 1, 0, relu2)
+        got2, got3 = dense.conv2d_forward_chain(x, w, b, w2, b2, res, relu=True, relu2=relu2, w3=w3, bias3=b3, relu3=relu2)
+        assert torch.equal(got2, ref)
+        assert torch.equal(got3, ref3), (N, H, W, Cin, (got3.float() - ref3.float()).abs().max().item())
     with pytest.raises(Exception):
         dense.conv2d_forward_chain(x, w, b, w2[:128].contiguous(), None, None)      # cout2 must be 256
 

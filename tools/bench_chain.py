@@ -49,5 +49,21 @@ def timeit(fn, cold):
     return run(gr) - (run(gz) if cold else 0.0)
 
 
+w3 = (torch.randn((64, 1, 1, 256), device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+b3 = torch.randn((64,), device="cuda", generator=g)
+a1n = torch.empty((N, H, W, 64), device="cuda", dtype=torch.bfloat16)
+
+
+def three():
+    two()
+    dense.conv2d_forward(y, w3, b3, None, 1, 0, True, False, a1n)
+
+
+def one3():
+    dense.conv2d_forward_chain(x, w, b, w2, b2, res, True, True, y, w3=w3, bias3=b3, relu3=True, out3=a1n)
+
+
+for cold in (False, True):
+    print("%s: + next conv1: three launches %.1f us, chained %.1f us" % ("cold" if cold else "warm", timeit(three, cold), timeit(one3, cold)))
 for cold in (False, True):
     print("%s: two launches %.1f us, chained %.1f us" % ("cold (1 GiB overwritten before each)" if cold else "warm", timeit(two, cold), timeit(one, cold)))
