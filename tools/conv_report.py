@@ -31,6 +31,10 @@ def main():
         if plan is not None:     # grouped launch: (layers in the group, -, -, 0, 0)
             key = (plan.n, 0, 0, 0, 0)
             family = family + "_grouped"
+        elif "chained" in _shape:   # conv2d_forward_chain: 3x3 -> 1x1 (-> next 1x1) in one launch; N column = the 1x1's columns
+            x, w, w2 = a[0], a[1], a[3]
+            key = (x.shape[0] * x.shape[1] * x.shape[2], w2.shape[0], w.shape[1] * w.shape[2] * w.shape[3], 3, 1)
+            family = family + "_chain"
         elif family == "conv_igemm_fwd":
             x, w = a[0], a[1]
             stride = kw.get("stride", a[4] if len(a) > 4 else 1)
