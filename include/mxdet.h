@@ -413,6 +413,12 @@ int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, 
 int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
                                int32_t grid_reduce, void* workspace, size_t workspace_bytes, size_t workspace_needed,
                                mxdet_stream_t stream);
+/* The same launch in parts (bit 0: the three-tap kernel of the 3x3 / stride 1 items, grid_big workgroups; bit 1: the
+ * one-tap kernel + bias workgroups, grid_wgrad; bit 2: the fold). The two tile kernels are independent of each other
+ * (the 3x3 tiles are MFMA-bound, the 1x1 tiles HBM-bound: a caller may issue them on two streams); the fold needs both. */
+int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
+                                     int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
+                                     size_t workspace_needed, mxdet_stream_t stream);
 /* Fused backward launch: the data-gradient tiles of a planned conv group (kind 1, tile cfg 2 or 3; table, cfg and
  * grid from mxdet_conv2d_grouped_plan) and the weight-gradient tiles [w_block_begin, w_block_end) of a planned wgrad
  * group in ONE grid, so that both kinds of workgroups share the CUs (small-map dgrad launches leave half the chip idle

@@ -31,11 +31,10 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_WG_TARGET 3    /* grouped wgrad: workgroups per group aimed for (default 3072) */
 #define MXDET_TUNE_WG_MINSTEPS 4  /* grouped wgrad: fewest 32-pixel steps per workgroup (default 64) */
 #define MXDET_TUNE_WG_MAXSTEPS 5  /* grouped wgrad: most steps per workgroup (default 128) */
-#define MXDET_TUNE_WGB_ENABLE 6   /* grouped wgrad: 1 = items with Cout, Cin >= 256 use the 256x256-tile kernel (default 0:
-                                     measured 16 % faster on the P2-sized layers alone, 0.1-1 % slower on the whole step) */
-#define MXDET_TUNE_WGB_TARGET 7   /* ... workgroups of that kernel per group aimed for (default 512) */
-#define MXDET_TUNE_WGB_MINSTEPS 8 /* ... fewest 64-pixel steps per workgroup (default 16) */
-#define MXDET_TUNE_WGB_MINPX 9    /* ... only for items with at least this many output pixels (default 100000) */
+#define MXDET_TUNE_T3_ENABLE 6    /* wgrad: 1 = 3x3 / stride 1 / pad 1 layers use the three-tap tile (wgrad3_tile.h; default 1) */
+#define MXDET_TUNE_T3_TARGET 7    /* ... workgroups of that kernel per group aimed for (default 1536) */
+#define MXDET_TUNE_T3_MINSTEPS 8  /* ... fewest 64-pixel steps per workgroup (default 16) */
+#define MXDET_TUNE_T3_NS 9        /* ... LDS-DMA ring depth, 2 or 3 (default 2) */
 #define MXDET_TUNE_TAIL 10        /* conv: tiles of the rows left over by the 256x256 rounds: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
 #define MXDET_TUNE_WG_NS 11       /* grouped wgrad (128x128 tiles): LDS-DMA ring depth 2, 3 or 4 */
 #define MXDET_TUNE_ROI_TABLE 12   /* RoIAlign backward (gather): 1 = the three-kernel table form instead of the segment form */
@@ -43,7 +42,9 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_STATIC_TAPS 14 /* conv: 1 = stride-1 1x1 / 3x3 layers use the unrolled static-tap K loop (default 1) */
 #define MXDET_TUNE_T128W 15     /* conv: stride-1 1x1 / 3x3 layers of >= 128 columns use 128x128 tiles of eight waves from this many
                                     128x128 tiles on (default 1000000 = never; measured in profiles/r02_d_static_cfg_sweep.txt) */
-#define MXDET_TUNE_COUNT 16
+#define MXDET_TUNE_T3_MIX 16    /* grouped wgrad: three-tap and one-tap tiles in ONE grid (0 = two launches; 1 = one-tap ring of 3
+                                    stages inside the three-tap kernel's LDS; 2 = ring of 2; default 1) */
+#define MXDET_TUNE_COUNT 17
 int mxdet_debug_set_tuning(int32_t which, int64_t value);
 
 #ifdef __cplusplus

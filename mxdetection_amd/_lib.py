@@ -137,6 +137,7 @@ SIGNATURES = {
     "mxdet_conv2d_wgrad_grouped_table_bytes": (c_sz, [c_i32]),
     "mxdet_conv2d_wgrad_grouped_plan": (c_i32, [P(WgradItemT), c_i32, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32), P(c_i32)]),
     "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
+    "mxdet_conv2d_wgrad_grouped_parts": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_debug_force_wgrad_ksplit": (c_i32, [c_i32]),
     "mxdet_fused_dgrad_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -172,9 +173,9 @@ SIGNATURES = {
 # entries declared in include/mxdet_debug.h (tuning / test hooks, not part of the drop-in boundary)
 DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
                  "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
-TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "WGB_ENABLE": 6,
-               "WGB_TARGET": 7, "WGB_MINSTEPS": 8, "WGB_MINPX": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14,
-               "T128W": 15}
+TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "T3_ENABLE": 6,
+               "T3_TARGET": 7, "T3_MINSTEPS": 8, "T3_NS": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14,
+               "T128W": 15, "T3_MIX": 16}
 
 _lib = None
 

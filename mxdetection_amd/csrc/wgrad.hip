@@ -23,7 +23,7 @@
 
 #include "common.h"
 #include "wgrad_tile.h"
-#include "wgrad_big.h"
+#include "wgrad3_tile.h"
 
 namespace mxdet {
 
@@ -65,10 +65,18 @@ wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __r
   }
 }
 
-// the 256 x 256 tiles of a group (wgrad_big.h): 512 threads, 128 KiB of LDS, one workgroup per CU
-__global__ void __launch_bounds__(512)
-wgrad_grouped_big_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[kBigLds];
+// the three-tap tiles (wgrad3_tile.h): 256 threads, NS * 25 KiB of LDS, two workgroups per CU
+template <int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad3_kernel(WgradP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * kT3Stage];
+  wgrad3_tile<NS>(p, (int)blockIdx.x, smem);
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad3_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * kT3Stage];
   const int bid = (int)blockIdx.x;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -79,7 +87,47 @@ wgrad_grouped_big_kernel(const WgradG* __restrict__ table, int n, unsigned char*
   if (b >= table[lo].bnblocks) return;             // alignment padding between layers
   WgradP p = table[lo].p;
   p.slab = (float*)(workspace + (size_t)p.slab);
-  wgrad_big_tile(p, b, smem);
+  wgrad3_tile<NS>(p, b, smem);
+}
+
+// Both tile kinds of a group in ONE grid. The 3x3 tiles are MFMA-bound, the 1x1 / strided tiles mostly HBM-bound (a 1x1
+// layer reads x and dy once for Cin*Cout/(Cin+Cout) flop per byte): as two launches in a row each phase leaves the other
+// resource idle (measured: the three-tap kernel at 1.24 PFLOP/s in the step, the one-tap kernel behind it at 0.4), mixed
+// in one grid a CU holds one workgroup of each kind. Groups of 8 workgroups (one per XCD) alternate between the two lists
+// in proportion to their lengths (n3g : n1g groups), so that both lists run out together.
+template <int NS3, int NS1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_mixed_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace, int n3g, int n1g) {
+  constexpr int kLds = NS3 * kT3Stage > NS1 * 2 * kWgradBKP * 256 ? NS3 * kT3Stage : NS1 * 2 * kWgradBKP * 256;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kLds];
+  const int G = (int)blockIdx.x >> 3, x8 = (int)blockIdx.x & 7, T = n3g + n1g;
+  const int a = (int)(((long long)G * n3g) / T), a2 = (int)(((long long)(G + 1) * n3g) / T);
+  if (a2 > a) {                                       // the a-th group of three-tap tiles
+    const int bid = a * 8 + x8;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (table[mid].bblock0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int b = bid - table[lo].bblock0;
+    if (b >= table[lo].bnblocks) return;             // alignment padding between layers
+    WgradP p = table[lo].p;
+    p.slab = (float*)(workspace + (size_t)p.slab);
+    wgrad3_tile<NS3>(p, b, smem);
+  } else {                                            // the (G - a)-th group of one-tap tiles / bias workgroups
+    const int bid = (G - a) * 8 + x8;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int b = bid - table[lo].block0;
+    if (b >= table[lo].nblocks) return;
+    WgradP p = table[lo].p;
+    p.slab = (float*)(workspace + (size_t)p.slab);
+    p.bslab = (float*)(workspace + (size_t)p.bslab);
+    wgrad_tile<kWgradBKP, NS1, true>(p, b, smem);
+  }
 }
 
 // dw[i] (+)= sum_ks slab[ks][i] in index order; the trailing workgroups fold the bias partials the same way.
@@ -257,6 +305,8 @@ filter_transpose_batched_kernel(const TransposeDesc* __restrict__ descs, int nde
 
 struct WgradPlan {
   int co_tiles, ci_tiles, taps, ksplit, steps_per_split;
+  int t3;                    // three-tap tiles (wgrad3_tile.h): ksplit / steps_per_split count 32-pixel steps all the same
+  int t3_ci_tiles, t3_steps;
   size_t slab_bytes, bslab_off, bslab_bytes, total;
 };
 
@@ -283,6 +333,22 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
   if (g_force_ksplit > 0) ks = g_force_ksplit < steps ? g_force_ksplit : steps;
   w.steps_per_split = ceil_div(steps, ks);
   w.ksplit = ceil_div(steps, w.steps_per_split);
+  w.t3 = tuning(MXDET_TUNE_T3_ENABLE) != 0 && wgrad3_eligible(d->KH, d->KW, d->stride, d->pad, d->H, d->W);
+  w.t3_ci_tiles = ceil_div(d->Cin, 64);
+  w.t3_steps = 0;
+  if (w.t3) {
+    // 512 workgroups are resident at once (two per CU); one full round if the layer has the pixels for it
+    const int steps3 = (int)ceil_div<long long>(wgrad3_vpixels(d->N, d->H, d->W), kT3Px);
+    const int tiles3 = w.co_tiles * w.t3_ci_tiles * 3;
+    int want3 = 512 / tiles3 > 0 ? 512 / tiles3 : 1;
+    const int max3 = steps3 / 8 > 0 ? steps3 / 8 : 1;          // at least 512 pixels per split
+    int ks3 = want3 < max3 ? want3 : max3;
+    ks3 = ks3 > 64 ? 64 : ks3;
+    if (g_force_ksplit > 0) ks3 = g_force_ksplit < steps3 ? g_force_ksplit : steps3;
+    w.t3_steps = ceil_div(steps3, ks3);
+    w.ksplit = ceil_div(steps3, w.t3_steps);
+    w.steps_per_split = ceil_div(steps, w.ksplit);              // the bias workgroups: any partition into ksplit ranges
+  }
   size_t params = (size_t)d->Cout * w.taps * d->Cin;
   w.slab_bytes = align_up((size_t)w.ksplit * params * sizeof(float), 256);
   w.bslab_off = w.slab_bytes;
@@ -294,12 +360,6 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
 }  // namespace mxdet
 
 using namespace mxdet;
-
-#ifdef MXDET_WGB_STAMP
-extern "C" int mxdet_debug_read_wgb_stamps(unsigned long long* out /* host, 48 */) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgb_stamp), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -4;
-}
-#endif
 
 extern "C" int mxdet_debug_wgrad_group_persist(int32_t workgroups) {
   g_group_persist = workgroups;
@@ -355,12 +415,23 @@ extern "C" int mxdet_conv2d_wgrad(const mxdet_conv_desc_t* d, const uint16_t* x,
   p.co_tiles = w.co_tiles; p.ci_tiles = w.ci_tiles; p.ksplit = w.ksplit;
   p.steps_per_split = w.steps_per_split;
   long long nwg = tiles * w.ksplit;
+  p.t3_nwg = 0; p.t3_ci_tiles = w.t3_ci_tiles; p.t3_ksplit = w.ksplit; p.t3_steps = w.t3_steps;
+  if (w.t3) {
+    // three-tap tiles first; the one-tap kernel keeps only the bias workgroups (same pixel ranges)
+    p.t3_nwg = w.co_tiles * w.t3_ci_tiles * 3 * w.ksplit;
+    p.nwg_main = 0;
+    if (tuning(MXDET_TUNE_T3_NS) == 3)
+      hipLaunchKernelGGL((wgrad3_kernel<3>), dim3((unsigned)p.t3_nwg), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((wgrad3_kernel<2>), dim3((unsigned)p.t3_nwg), dim3(256), 0, s, p);
+    nwg = 0;
+  }
   p.nwg_main = (int)nwg;
   if (db) nwg += (long long)w.co_tiles * w.ksplit;
   // few workgroups per CU: a deeper ring hides the load latency that co-resident workgroups would otherwise hide
-  if (nwg <= 2 * 256)
+  if (nwg > 0 && nwg <= 2 * 256)
     hipLaunchKernelGGL((wgrad_kernel<kWgradBKP, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p);
-  else
+  else if (nwg > 0)
     hipLaunchKernelGGL((wgrad_kernel<kWgradBKP, 2>), dim3((unsigned)nwg), dim3(256), 0, s, p);
   if (w.ksplit > 1) {
     long long params = (long long)d->Cout * w.taps * d->Cin;
@@ -405,29 +476,26 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
   // pixels per workgroup: long enough K loops to amortise the 64-KiB slab a workgroup writes, short enough that the
   // group has a few thousand workgroups; never below 16 steps
   long long tiles_total = 0;
-  // Items wide enough for the 256 x 256 tile go to the 512-thread kernel. All of them get the same step count S per
+  // 3x3 / stride 1 / pad 1 items go to the three-tap kernel (wgrad3_tile.h). All of them get the same step count S per
   // workgroup (64-pixel steps), the smallest S >= the minimum for which the group has at most the target number of
-  // workgroups: equal-length workgroups pack the rounds of 256 CUs evenly, whatever the map size of their layer.
-  const bool use_big = tuning(MXDET_TUNE_WGB_ENABLE) != 0;
-  // ... and long enough: a 256 x 256 workgroup costs ~13 us before and after its K loop (table lookup, first loads,
-  // 256 KiB of fp32 partial sums), which only the P2 / P3-sized maps amortise (tools/bench_wgrad.py)
-  const long long big_minpx = tuning(MXDET_TUNE_WGB_MINPX);
+  // workgroups: equal-length workgroups pack the rounds of the 512 resident ones evenly, whatever the map size.
+  const bool use_t3 = tuning(MXDET_TUNE_T3_ENABLE) != 0;
   auto is_big = [&](const mxdet_conv_desc_t& d) {
-    return use_big && d.Cout >= 256 && d.Cin >= 256 && (long long)d.N * d.Ho * d.Wo >= big_minpx;
+    return use_t3 && wgrad3_eligible(d.KH, d.KW, d.stride, d.pad, d.H, d.W);
   };
   int big_S = 0;
   {
-    const long long target = tuning(MXDET_TUNE_WGB_TARGET);
-    const int smin = (int)tuning(MXDET_TUNE_WGB_MINSTEPS);
+    const long long target = tuning(MXDET_TUNE_T3_TARGET);
+    const int smin = (int)tuning(MXDET_TUNE_T3_MINSTEPS);
     auto count = [&](int S) {
       long long c = 0;
       for (int i = 0; i < n; ++i) {
         const mxdet_conv_desc_t& d = items[i].desc;
         if (!is_big(d)) continue;
-        const long long steps = ceil_div<long long>((long long)d.N * d.Ho * d.Wo, kBigPx);
+        const long long steps = ceil_div<long long>(wgrad3_vpixels(d.N, d.H, d.W), kT3Px);
         long long ks = ceil_div<long long>(steps, S);
         ks = ks > 64 ? 64 : ks;
-        c += (long long)ceil_div(d.Cout, 256) * ceil_div(d.Cin, 256) * d.KH * d.KW * ks;
+        c += (long long)ceil_div(d.Cout, 128) * ceil_div(d.Cin, 64) * 3 * ks;
       }
       return c;
     };
@@ -460,28 +528,28 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
     p.co_tiles = ceil_div(d->Cout, 128); p.ci_tiles = ceil_div(d->Cin, 128);
     const int taps = d->KH * d->KW;
     if (is_big(*d)) {
-      const int bsteps = ceil_div(p.M, kBigPx);
+      const int bsteps = (int)ceil_div<long long>(wgrad3_vpixels(d->N, d->H, d->W), kT3Px);   // virtual pixels (pad per row)
       int ks = ceil_div(bsteps, big_S);
       ks = ks > 64 ? 64 : ks;
-      p.big_steps_per_split = ceil_div(bsteps, ks);
-      p.big_ksplit = ceil_div(bsteps, p.big_steps_per_split);
-      p.big_co_tiles = ceil_div(d->Cout, 256); p.big_ci_tiles = ceil_div(d->Cin, 256);
-      p.big_nwg = p.big_co_tiles * p.big_ci_tiles * taps * p.big_ksplit;
-      // the bias partial sums stay with the 256-thread kernel, over the same pixel ranges
-      p.ksplit = p.big_ksplit;
-      p.steps_per_split = p.big_steps_per_split * (kBigPx / kWgradBKP);
+      p.t3_steps = ceil_div(bsteps, ks);
+      p.t3_ksplit = ceil_div(bsteps, p.t3_steps);
+      p.t3_ci_tiles = ceil_div(d->Cin, 64);
+      p.t3_nwg = p.co_tiles * p.t3_ci_tiles * 3 * p.t3_ksplit;
+      // the bias partial sums stay with the one-tap kernel, over the same pixel ranges
+      p.ksplit = p.t3_ksplit;
+      p.steps_per_split = ceil_div(ceil_div(p.M, kWgradBKP), p.ksplit);   // any partition of the pixels into ksplit ranges
       p.nwg_main = 0;
       g.nparams = (long long)d->Cout * taps * d->Cin;
       g.nblocks = p.db ? p.co_tiles * p.ksplit : 0;
       g.block0 = (int)blocks;
       blocks += align_up((size_t)g.nblocks, 8);
-      g.bnblocks = p.big_nwg;
+      g.bnblocks = p.t3_nwg;
       g.bblock0 = (int)bblocks_total;
       bblocks_total += align_up((size_t)g.bnblocks, 8);
       MXDET_REQUIRE(blocks < (1ll << 30) && bblocks_total < (1ll << 30), MXDET_ESHAPE, "wgrad_grouped_plan: group too large");
       continue;
     }
-    g.bblock0 = (int)bblocks_total;      // no 256 x 256 tiles: an empty range keeps the table sorted for the search
+    g.bblock0 = (int)bblocks_total;      // no three-tap tiles: an empty range keeps the table sorted for the search
     g.bnblocks = 0;
     const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
     const int steps = ceil_div(p.M, kWgradBKP);
@@ -555,8 +623,26 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
 extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
                                           int32_t grid_reduce, void* workspace, size_t workspace_bytes,
                                           size_t workspace_needed, mxdet_stream_t stream) {
+  return mxdet_conv2d_wgrad_grouped_parts(table_dev, n, grid_wgrad, grid_big, grid_reduce, 7, workspace, workspace_bytes,
+                                          workspace_needed, stream);
+}
+
+// parts: bit 0 = the three-tap kernel, bit 1 = the one-tap kernel (+ bias workgroups), bit 2 = the fold. The two tile
+// kernels are independent of each other (a caller may issue them on two streams: the 3x3 tiles are MFMA-bound, the 1x1
+// tiles HBM-bound); the fold needs both.
+extern "C" int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
+                                                int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
+                                                size_t workspace_needed, mxdet_stream_t stream) {
   clear_error();
-  MXDET_REQUIRE(table_dev && n > 0 && grid_wgrad >= 0 && grid_big >= 0 && grid_wgrad + grid_big > 0, MXDET_EINVAL,
+  if (!(parts & 1)) grid_big = 0;
+  if (!(parts & 4)) grid_reduce = 0;
+  if (!(parts & 2)) {
+    if (grid_big == 0 && grid_reduce == 0) return MXDET_OK;
+    grid_wgrad = 0;
+  } else if (grid_wgrad == 0 && grid_big == 0 && grid_reduce == 0) {
+    return MXDET_OK;
+  }
+  MXDET_REQUIRE(table_dev && n > 0 && grid_wgrad >= 0 && grid_big >= 0 && grid_wgrad + grid_big + grid_reduce > 0, MXDET_EINVAL,
                 "wgrad_grouped: empty group");
   MXDET_REQUIRE(workspace_needed == 0 || (workspace && workspace_bytes >= workspace_needed), MXDET_EWORKSPACE,
                 "wgrad_grouped: workspace %zu < %zu", workspace_bytes, workspace_needed);
@@ -564,9 +650,25 @@ extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int3
   // Optional chunking (tuning hook): a grid far larger than one resident round keeps the dispatcher on this queue until
   // it has placed every workgroup, which starves the short dgrad kernels of the main stream; chunks of about one
   // resident round let the two queues alternate at launch granularity.
-  if (grid_big > 0)
-    hipLaunchKernelGGL(wgrad_grouped_big_kernel, dim3((unsigned)grid_big), dim3(512), 0, s, (const WgradG*)table_dev, n,
-                       (unsigned char*)workspace);
+  if (grid_big > 0 && grid_wgrad > 0 && tuning(MXDET_TUNE_T3_MIX) != 0 && (grid_big & 7) == 0 && (grid_wgrad & 7) == 0) {
+    const int n3g = grid_big >> 3, n1g = grid_wgrad >> 3;
+    if (tuning(MXDET_TUNE_T3_MIX) == 2)
+      hipLaunchKernelGGL((wgrad_mixed_grouped_kernel<2, 2>), dim3((unsigned)(grid_big + grid_wgrad)), dim3(256), 0, s,
+                         (const WgradG*)table_dev, n, (unsigned char*)workspace, n3g, n1g);
+    else
+      hipLaunchKernelGGL((wgrad_mixed_grouped_kernel<2, 3>), dim3((unsigned)(grid_big + grid_wgrad)), dim3(256), 0, s,
+                         (const WgradG*)table_dev, n, (unsigned char*)workspace, n3g, n1g);
+    grid_big = 0;
+    grid_wgrad = 0;
+  }
+  if (grid_big > 0) {
+    if (tuning(MXDET_TUNE_T3_NS) == 3)
+      hipLaunchKernelGGL((wgrad3_grouped_kernel<3>), dim3((unsigned)grid_big), dim3(256), 0, s, (const WgradG*)table_dev, n,
+                         (unsigned char*)workspace);
+    else
+      hipLaunchKernelGGL((wgrad3_grouped_kernel<2>), dim3((unsigned)grid_big), dim3(256), 0, s, (const WgradG*)table_dev, n,
+                         (unsigned char*)workspace);
+  }
   const int chunk = g_group_chunk > 0 ? g_group_chunk : (grid_wgrad > 0 ? grid_wgrad : 1);
   const int persist = g_group_persist > 0 ? (g_group_persist + 7) & ~7 : 0;
   for (int off = 0; off < grid_wgrad; off += chunk) {

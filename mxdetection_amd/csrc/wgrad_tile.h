@@ -25,10 +25,10 @@ struct WgradP {
   int M;               // N*Ho*Wo
   int co_tiles, ci_tiles, ksplit, steps_per_split;
   int nwg_main;        // MFMA workgroups; the grid continues with co_tiles*ksplit bias workgroups when db != null
-  // 256 x 256 tiles of the 512-thread kernel (wgrad_big.h; grouped launches only). An item is tiled by ONE of the two
-  // kernels: big_nwg > 0 means nwg_main == 0 and only the bias workgroups (if any) stay with the 256-thread kernel,
-  // with ksplit / steps_per_split describing the same pixel ranges as big_ksplit / big_steps_per_split.
-  int big_nwg, big_co_tiles, big_ci_tiles, big_ksplit, big_steps_per_split;
+  // three-tap tiles (wgrad3_tile.h; 3x3 / stride 1 / pad 1 layers). An item is tiled by ONE of the two kernels:
+  // t3_nwg > 0 means nwg_main == 0 and only the bias workgroups (if any) stay with the one-tap kernel, with ksplit /
+  // steps_per_split describing the same pixel ranges as t3_ksplit / t3_steps (64-pixel steps).
+  int t3_nwg, t3_ci_tiles, t3_ksplit, t3_steps;
 };
 
 // byte offset inside a [64 px][256 B] image of 16-B chunk c16 of pixel row `row`
@@ -309,7 +309,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
 struct WgradG {
   WgradP p;                 // slab / bslab hold byte offsets into the workspace
   int block0, nblocks;      // this layer's workgroups: [block0, block0 + nblocks), block0 a multiple of 8
-  int bblock0, bnblocks;    // the same in the 512-thread kernel's numbering (256 x 256 tiles)
+  int bblock0, bnblocks;    // the same in the three-tap kernel's numbering
   int rblock0, wblocks, bblocks;   // fold kernel: first workgroup, workgroups over dw, workgroups over db
   int fold_ksplit;                 // slabs the fold adds up (all items that share this item's dw write into one run)
   long long nparams;

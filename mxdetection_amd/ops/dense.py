@@ -251,14 +251,14 @@ class GroupedWgrad:
         nbytes = lib.mxdet_conv2d_wgrad_grouped_table_bytes(n)
         host = (C.c_ubyte * nbytes)()
         ws, gw, gb, gr = C.c_size_t(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        if fused:        # the fused backward launch slices the 256-thread kernel's tiles: no 256x256-tile items
-            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], 0)
+        if fused:        # the fused backward launch slices the 256-thread kernel's tiles: no three-tap items
+            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_ENABLE"], 0)
         try:
             check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gb),
                                                       C.byref(gr)), "conv2d_wgrad_grouped_plan")
         finally:
             if fused:
-                lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], -1)
+                lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_ENABLE"], -1)
         self.grid_big = gb.value
         self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
         self.n, self.grid_wgrad, self.grid_reduce, self.workspace_bytes = n, gw.value, gr.value, ws.value
@@ -272,10 +272,28 @@ class GroupedWgrad:
                                                           self.grid_reduce, ptr(workspace), workspace.numel(),
                                                           self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped_from")
 
-    def launch(self, workspace):
-        check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce,
-                                                     ptr(workspace), workspace.numel() if workspace is not None else 0,
-                                                     self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
+    def launch(self, workspace, side=None):
+        """side: a second stream for the one-tap kernel (1x1 / strided items, HBM-bound) so that it runs beside the
+        three-tap kernel (3x3 items, MFMA-bound) instead of behind it; the fold joins both."""
+        lib = _lib.load()
+        nb = workspace.numel() if workspace is not None else 0
+        if side is None or self.grid_big == 0 or self.grid_wgrad == 0:
+            check(lib.mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce,
+                                                 ptr(workspace), nb, self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
+            return
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            check(lib.mxdet_conv2d_wgrad_grouped_parts(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce, 2,
+                                                       ptr(workspace), nb, self.workspace_bytes, stream_ptr()),
+                  "conv2d_wgrad_grouped_parts")
+        check(lib.mxdet_conv2d_wgrad_grouped_parts(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce, 1,
+                                                   ptr(workspace), nb, self.workspace_bytes, stream_ptr()),
+              "conv2d_wgrad_grouped_parts")
+        cur.wait_stream(side)
+        check(lib.mxdet_conv2d_wgrad_grouped_parts(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce, 4,
+                                                   ptr(workspace), nb, self.workspace_bytes, stream_ptr()),
+              "conv2d_wgrad_grouped_parts")
 
 
 def filter_transpose(w, out=None):

@@ -339,21 +339,23 @@ def test_filter_transpose_batched_matches_permute(hip):
         assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
 
 
-def test_grouped_wgrad_big_tiles(hip, oracle):
-    """The 256x256-tile weight-gradient kernel (items with Cout, Cin >= 256 of a grouped launch) against torch-CPU fp32
-    on the same bf16 operands: partial tiles (448 output channels), stride 2, fully connected (1x1 maps), a filter shared
-    by two levels, bias gradients, kAddTo -- mixed in one group with an item of the 128x128-tile kernel. fp32
-    accumulation in a fixed order: rms-relative 1e-3."""
+def test_grouped_wgrad_three_tap_tiles(hip, oracle):
+    """The three-tap weight-gradient kernel (3x3 / stride 1 / pad 1 items of a grouped launch, wgrad3_tile.h) against
+    torch-CPU fp32 on the same bf16 operands: maps narrower and wider than a 64-pixel step, partial channel tiles (72 and
+    200 channels), one image, a filter shared by two levels, bias gradients, kAddTo -- mixed in one group with items of the
+    one-tap kernel (1x1, stride 2, fully connected). fp32 accumulation in a fixed order: rms-relative 1e-3."""
     import torch
     from mxdetection_amd.ops import dense
     rng = np.random.default_rng(33)
     torch.set_num_threads(8)
     # (N, H, W, Cin, Cout, K, stride, pad, bias)
     cases = [(2, 25, 42, 256, 256, 3, 1, 1, True),      # C4 conv2 shape, 2100 pixels
-             (2, 13, 21, 512, 448, 1, 1, 0, True),      # partial co tile (448 = 256 + 192)
-             (1, 26, 44, 256, 512, 3, 2, 1, False),     # stride 2
-             (300, 1, 1, 1024, 256, 1, 1, 0, True),     # fully connected: 300 rois, fewer than 5 steps
-             (2, 25, 42, 64, 128, 3, 1, 1, True)]       # narrow: stays with the 128x128-tile kernel
+             (2, 13, 21, 512, 448, 1, 1, 0, True),      # 1x1: one-tap kernel
+             (1, 26, 44, 256, 512, 3, 2, 1, False),     # stride 2: one-tap kernel
+             (300, 1, 1, 1024, 256, 1, 1, 0, True),     # fully connected: one-tap kernel
+             (2, 25, 42, 64, 128, 3, 1, 1, True),       # narrow
+             (1, 9, 130, 72, 200, 3, 1, 1, True),       # rows longer than a step, partial co / ci tiles, one image
+             (3, 12, 7, 128, 64, 3, 1, 1, False)]       # tiny maps: several rows inside one step, images inside a range
     calls, refs = [], []
     for N, H, W, Cin, Cout, K, s, pd, bias in cases:
         Ho, Wo = (H + 2 * pd - K) // s + 1, (W + 2 * pd - K) // s + 1
@@ -378,14 +380,7 @@ def test_grouped_wgrad_big_tiles(hip, oracle):
     gb_s = sum(d.reshape(-1, Cs).astype(np.float64).sum(0) for d in dys)
     for x, d in zip(xs, dys):
         calls.append((_t(x, torch.bfloat16), _t(d, torch.bfloat16), 3, 3, 1, 1, dw_s, db_s, False))
-    tune = hip.load().mxdet_debug_set_tuning
-    tune(hip.TUNING_KEYS["WGB_ENABLE"], 1)       # the kernel is off by default
-    tune(hip.TUNING_KEYS["WGB_MINPX"], 0)        # small maps too
-    try:
-        plan = dense.GroupedWgrad(calls, "cuda")
-    finally:
-        tune(hip.TUNING_KEYS["WGB_MINPX"], -1)
-        tune(hip.TUNING_KEYS["WGB_ENABLE"], -1)
+    plan = dense.GroupedWgrad(calls, "cuda")
     assert plan.grid_big > 0 and plan.grid_wgrad > 0          # both kernels take part
     ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
     plan.launch(ws)
@@ -406,11 +401,7 @@ def test_grouped_wgrad_big_tiles(hip, oracle):
     assert all(torch.equal(a, c[6]) for a, c in zip(first, calls))
     acc_calls = [c[:8] + (True,) for c in calls[:2]]
     base = [c[6].clone() for c in acc_calls]
-    tune(hip.TUNING_KEYS["WGB_ENABLE"], 1)
-    tune(hip.TUNING_KEYS["WGB_MINPX"], 0)
     plan2 = dense.GroupedWgrad(acc_calls, "cuda")
-    tune(hip.TUNING_KEYS["WGB_MINPX"], -1)
-    tune(hip.TUNING_KEYS["WGB_ENABLE"], -1)
     assert plan2.grid_big > 0
     ws2 = torch.empty((max(plan2.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
     plan2.launch(ws2)

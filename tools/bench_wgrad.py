@@ -1,4 +1,4 @@
-"""Grouped weight-gradient launch of ONE layer, 256x256-tile kernel vs 128x128-tile kernel, device time from a hipGraph
+"""Grouped weight-gradient launch of ONE layer, three-tap kernel (3x3 layers) vs one-tap 128x128-tile kernel, device time from a hipGraph
 replay between HIP events:  python tools/bench_wgrad.py [target] [minsteps]"""
 import os
 import sys
@@ -34,9 +34,9 @@ def time_graph(fn, reps=5):
 
 def main():
     if len(sys.argv) > 1:
-        lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_TARGET"], int(sys.argv[1]))
+        lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_TARGET"], int(sys.argv[1]))
     if len(sys.argv) > 2:
-        lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_MINSTEPS"], int(sys.argv[2]))
+        lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_MINSTEPS"], int(sys.argv[2]))
     g = torch.Generator(device="cuda").manual_seed(1)
     sel = os.environ.get("WG_SHAPES")          # e.g. "0,2": only these rows of SHAPES
     shapes = [SHAPES[int(i)] for i in sel.split(",")] if sel else SHAPES
@@ -49,7 +49,7 @@ def main():
         fl = 2.0 * N * H * W * Cout * K * K * Cin
         out = []
         for big in (1, 0):
-            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], big)
+            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_ENABLE"], big)
             plan = dense.GroupedWgrad([(x, dy, K, K, 1, pad, dw, None, False)], "cuda")
             ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
             if eager:

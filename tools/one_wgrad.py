@@ -12,11 +12,11 @@ lib = _lib.load()
 big = sys.argv[1] == "big"
 N, H, W, Cin, Cout, K = [int(v) for v in sys.argv[2:8]]
 if len(sys.argv) > 8:
-    lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_TARGET"], int(sys.argv[8]))
+    lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_TARGET"], int(sys.argv[8]))
 if len(sys.argv) > 9:
-    lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_MINSTEPS"], int(sys.argv[9]))
+    lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_MINSTEPS"], int(sys.argv[9]))
 reps = int(sys.argv[10]) if len(sys.argv) > 10 else 5
-lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["WGB_ENABLE"], int(big))
+lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_ENABLE"], int(big))
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn((N, H, W, Cin), device="cuda", generator=g).to(torch.bfloat16)
 dy = torch.randn((N, H, W, Cout), device="cuda", generator=g).to(torch.bfloat16)
@@ -27,18 +27,3 @@ print("grid big %d small %d reduce %d slabs %.1f MB" % (plan.grid_big, plan.grid
 for _ in range(reps):
     plan.launch(ws)
 torch.cuda.synchronize()
-if hasattr(lib, "mxdet_debug_read_wgb_stamps"):
-    import ctypes as C
-    buf = (C.c_uint64 * 48)()
-    lib.mxdet_debug_read_wgb_stamps(buf)
-    names = ["issue", "vmwait", "reads+bar1+lgkm", "mfma", "bar2"]
-    for grp in range(2):
-        v = list(buf[grp * 24:(grp + 1) * 24])
-        n = max(1, v[23])
-        print("group %s: %d steps" % ("AB"[grp], n))
-        tot = 0
-        for ph in range(4):
-            row = [v[ph * 5 + k] / n for k in range(5)]
-            tot += sum(row)
-            print("  phase %d: " % ph + "  ".join("%s %6.0f" % (nm, x) for nm, x in zip(names, row)))
-        print("  cycles per step: %.0f" % tot)
