@@ -116,10 +116,10 @@ class ConvTimer:
         orig_launch = dense.GroupedWgrad.launch
         timer.orig["GroupedWgrad.launch"] = orig_launch
 
-        def grouped_launch(plan, workspace):
+        def grouped_launch(plan, workspace, *rest):
             if timer.logging:
                 timer.log.append(("conv_wgrad", plan.flops, orig_launch, (plan, workspace), {}, "group of %d layers" % plan.n))
-            return orig_launch(plan, workspace)
+            return orig_launch(plan, workspace, *rest)
         dense.GroupedWgrad.launch = grouped_launch
         orig_glaunch = dense.GroupedConv.launch
         timer.orig["GroupedConv.launch"] = orig_glaunch
@@ -171,6 +171,80 @@ def cpu_baseline(rank):
     except Exception as ex:  # noqa: BLE001
         return {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "unavailable: %r" % (ex,)}
     return model_ref.timed_cpu_baseline()
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: tracked counter summaries (profiles/*_pmc_step.json) carry it, a stale one yields null."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mxdetection_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_family(name):
+    """conv family of a kernel name of the trace (None: not a conv kernel)."""
+    import re
+    m = re.search(r"conv_igemm(?:_grouped)?_kernel<([^>]*)>", name)
+    if m:
+        return "conv_igemm_dgrad" if m.group(1).split(",")[5].strip() == "true" else "conv_igemm_fwd"
+    if "wgrad" in name:
+        return "conv_wgrad"
+    return None
+
+
+def instep_profile(model, timeout_s=240):
+    """Kernel durations INSIDE replayed steps: a child process runs a short replay of the same model under
+    `rocprofv3 --kernel-trace` (started before this process touches the GPU, like the ranks of --gpus N); the trace's
+    complete steps (a step starts at the stem kernel) give per-family device time as it is in the step: cold operands,
+    the other streams' kernels beside it. Returns None when the profiler is not available or fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    d = tempfile.mkdtemp(prefix="mxdet_instep_", dir="/tmp")
+    try:
+        cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "tl", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-conv-timer", "--no-cpu-baseline", "--no-instep",
+               "--model", model]
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        files = glob.glob(os.path.join(d, "**", "tl_kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        rows = []
+        with open(files[0]) as f:
+            for x in csv.DictReader(f):
+                rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"]))
+        rows.sort()
+        stems = [i for i, x in enumerate(rows) if "stem_pool_kernel" in x[2] or "stem_conv_kernel" in x[2]]
+        if len(stems) < 4:
+            return None
+        steps = list(zip(stems[-4:-1], stems[-3:]))       # the last three complete steps
+        fam, wall = {}, 0.0
+        for lo, hi in steps:
+            win = rows[lo:hi]
+            wall += (rows[hi][0] - win[0][0]) * 1e-6
+            for s0, e0, name in win:
+                k = kernel_family(name)
+                if k:
+                    acc = fam.setdefault(k, [0.0, 0])
+                    acc[0] += (e0 - s0) * 1e-6
+                    acc[1] += 1
+        n = float(len(steps))
+        return {"families_ms": {k: v[0] / n for k, v in fam.items()}, "kernels": {k: v[1] / n for k, v in fam.items()},
+                "step_ms": wall / n, "steps": len(steps)}
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def spawn_ranks(n):
@@ -227,6 +301,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timer", action="store_true")
+    ap.add_argument("--no-instep", action="store_true",
+                    help="skip the in-step kernel timing (a child run under rocprofv3 --kernel-trace before the timed run)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the main stream")
     ap.add_argument("--no-branch-stream", action="store_true", help="keep the RPN training branch on the main stream")
@@ -245,8 +321,14 @@ def main():
         # anything here touches the GPU (no torch import yet), relays rank 0's JSON line and fails if any rank fails.
         sys.exit(spawn_ranks(args.gpus))
 
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    instep = None
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if world == 1 and args.gpus == 1 and not (args.no_instep or args.no_conv_timer or args.no_graph or under_profiler) \
+            and args.input == "resident":
+        instep = instep_profile(args.model)       # before this process touches the GPU
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()          # does not initialise the GPU
@@ -391,29 +473,46 @@ def main():
         per_gpu = value / world
         roofline = None
         families = {}
+        hbm_frac = None
         if fam:
-            dom = max(fam.items(), key=lambda kv: kv[1][1])
+            # time of a family = its kernels' device time INSIDE replayed steps when the in-step trace exists (time_source
+            # says which); the warm figure (each launch re-issued back to back) stays beside it as warm_tflops
+            ist = instep["families_ms"] if instep else {}
             for k, (fl, tt, n) in fam.items():
-                families[k] = {"launches_per_step": n, "avg_ms": round(1e3 * tt / max(n, 1), 4),
-                               "tflops": round(fl / tt / 1e12, 1), "ms_per_step": round(1e3 * tt, 3),
-                               "share_of_step": round(tt / (dt / args.steps), 3)}
-            fl, tt, n = dom[1]
-            roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(fl / tt / 1e12, 2), "peak": 2500.0,
-                        "unit": "TFLOP/s", "frac": round(fl / tt / MFMA_PEAK_BF16, 4), "traffic": None,
-                        "launches_per_step": n, "avg_launch_ms": round(1e3 * tt / n, 4),
-                        "method": "each conv launch of one step re-issued 8x inside a hipGraph replayed between HIP events"}
+                t_in = ist.get(k, 0.0) * 1e-3
+                t_use = t_in if t_in > 0 else tt
+                families[k] = {"launches_per_step": n, "avg_ms": round(1e3 * t_use / max(n, 1), 4),
+                               "tflops": round(fl / t_use / 1e12, 1), "ms_per_step": round(1e3 * t_use, 3),
+                               "share_of_step": round(t_use / (dt / args.steps), 3),
+                               "warm_tflops": round(fl / tt / 1e12, 1), "warm_ms_per_step": round(1e3 * tt, 3)}
+            dom = max(families.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
+            fl, tt, n = fam[dom]
+            t_use = families[dom]["ms_per_step"] * 1e-3
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / t_use / 1e12, 2), "peak": 2500.0,
+                        "unit": "TFLOP/s", "frac": round(fl / t_use / MFMA_PEAK_BF16, 4), "traffic": None,
+                        "launches_per_step": n, "avg_launch_ms": round(1e3 * t_use / n, 4),
+                        "time_source": ("in-step: rocprofv3 --kernel-trace of %d replayed steps (child process of this run, "
+                                        "step %.3f ms under the profiler)" % (instep["steps"], instep["step_ms"])) if instep else
+                                       "warm: each conv launch of one step re-issued 8x inside a hipGraph replayed between HIP events",
+                        "warm_frac": round(fl / tt / MFMA_PEAK_BF16, 4),
+                        "flops_source": "2*M*N*K of every launch of the family logged in one eager step"}
         # `traffic` = HBM-side bytes (L2 misses) of the WHOLE dominant family in one step, from the tracked summary of
         # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over an eager step (tools/pmc_step.sh; FETCH_SIZE
         # doubled for 16-B-per-lane reads as the microarch guide prescribes). It is measured evidence of this round's
-        # kernels, not of this very run: `traffic_source` names the file.
+        # kernels, not of this very run: `traffic_source` names the file, and the file carries the hash of the kernel
+        # sources it was measured on -- after a kernel change the stale figure is dropped (null), not reported.
         if roofline is not None and args.model == "faster_rcnn":
-            src = os.path.join("profiles", "r02_pmc_step.json")
+            src = os.path.join("profiles", "r03_pmc_step.json")
             try:
                 with open(os.path.join(ROOT, src)) as f:
                     pm = json.load(f)
+                if pm.get("csrc_sha16") != csrc_sha16():
+                    raise ValueError("stale counter summary")
                 roofline["traffic"] = pm["families"][roofline["kernel"]]["hbm_bytes"]
                 roofline["traffic_source"] = src
                 roofline["traffic_scope"] = "all %d launches of the family in one step" % pm["families"][roofline["kernel"]]["launches_per_step"]
+                total = sum(v.get("hbm_bytes", 0) for v in pm["kernels"].values())
+                hbm_frac = round(total / (dt / args.steps) / 8.0e12, 4)    # all kernels of the step / step time / 8 TB/s
             except Exception:  # noqa: BLE001
                 roofline["traffic"] = None
         if roofline is not None and timer.heaviest.get(roofline["kernel"]):
@@ -445,6 +544,7 @@ def main():
             "losses_last_step": loss_vals,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
             "roofline": roofline,
+            "hbm_frac": hbm_frac,
             "conv_families": families,
         }
         if world == 1 and not args.no_cpu_baseline:

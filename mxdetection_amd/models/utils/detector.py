@@ -175,8 +175,6 @@ class DetectorBase:
     def enable_wgrad_stream(self):
         """Issue weight-gradient kernels on a second stream (overlaps them with the data-gradient chain)."""
         self.ws.side = torch.cuda.Stream()
-        if os.environ.get("MXDET_WG_SPLIT", "0") == "1":      # one-tap kernel of a grouped launch beside the three-tap one
-            self.ws.side2 = torch.cuda.Stream()
 
     def enable_branch_stream(self):
         """Run the RPN training branch on its own stream, concurrently with the proposal / RoI-head chain."""

@@ -44,8 +44,6 @@ class Workspace:
         self.buf = None
         self._retired = []
         self.side = None
-        # a third stream for the one-tap kernel of a grouped launch (GroupedWgrad.launch), created with the side stream
-        self.side2 = None
         # grouped mode: backward_weight() calls are recorded and issued together at flush() (one launch pair per
         # group -- a ResNet stage, the FPN, a head -- instead of two launches per layer)
         self.grouping = False
@@ -121,7 +119,7 @@ class Workspace:
                     dense.conv2d_wgrad(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
                                        l.arena.view(l.bi, "g") if l.train_bias else None, False, self.get())
             else:
-                plan.launch(self.gbuf, self.side2)
+                plan.launch(self.gbuf)
         if self.fusing and plan is not None and not capturing:
             # remember this bucket for the next pass; fused launches write its slabs from the main stream while the
             # previous bucket's fold may still be reading: every bucket gets a slab buffer of its own

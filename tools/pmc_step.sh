@@ -9,7 +9,7 @@ mkdir -p gpurun_out/$tag
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  (cd /tmp && timeout -k 10 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/$tag/pass$i -o c -- python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-conv-timer --no-cpu-baseline "$@" > $R/gpurun_out/$tag/pass$i.log 2>&1)
+  (cd /tmp && timeout -k 10 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/$tag/pass$i -o c -- python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-conv-timer --no-cpu-baseline --no-instep "$@" > $R/gpurun_out/$tag/pass$i.log 2>&1)
   echo "pass $i ($ctrs) done"
 done
 python tools/pmc_summary.py gpurun_out/$tag gpurun_out/$tag/pmc_step.json

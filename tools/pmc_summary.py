@@ -21,7 +21,7 @@ def family(name):
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
         return ("conv_igemm_dgrad" if args[5] == "true" else "conv_igemm_fwd") + " %sx%s" % (args[0], args[1]) + ("g" if m.group(1) else "")
-    for key in ("wgrad_grouped_big_kernel", "wgrad_grouped_kernel", "wgrad_reduce_grouped_kernel", "wgrad_kernel", "stem_pool_kernel",
+    for key in ("wgrad_mixed_grouped_kernel", "wgrad3_grouped_kernel", "wgrad3_kernel", "wgrad_grouped_kernel", "wgrad_reduce_grouped_kernel", "wgrad_kernel", "stem_pool_kernel",
                 "roi_align_bwd_gather_kernel", "roi_bwd_tab_kernel", "roi_bwd_rows_kernel", "roi_bwd_seg_kernel", "roi_bwd_box_kernel",
                 "roi_align_fwd_kernel", "sgd_kernel",
                 "filter_transpose_batched_kernel", "nms_scan_rows_kernel", "nms_mask_kernel", "proposal_", "anchor_", "rpn_loss_kernel",
@@ -31,7 +31,7 @@ def family(name):
     return "other"
 
 
-WIDE = ("conv_igemm", "wgrad_grouped", "wgrad_kernel", "wgrad_reduce", "sgd_kernel", "filter_transpose", "upsample2")
+WIDE = ("conv_igemm", "wgrad_mixed", "wgrad3", "wgrad_grouped", "wgrad_kernel", "wgrad_reduce", "sgd_kernel", "filter_transpose", "upsample2")
 
 
 def main():
@@ -89,7 +89,10 @@ def main():
         keys = [k for k in res if (k.startswith("wgrad") if grp == "conv_wgrad" else k.startswith(grp))]
         agg[grp] = {"hbm_bytes": sum(res[k].get("hbm_bytes", 0) for k in keys), "launches_per_step": sum(res[k]["launches_per_step"] for k in keys),
                     "members": keys}
-    json.dump({"note": "one eager training step, Faster R-CNN R50-FPN batch 2 (bench.py --no-graph); counters per kernel family, "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    json.dump({"csrc_sha16": bench.csrc_sha16(),
+               "note": "one eager training step, Faster R-CNN R50-FPN batch 2 (bench.py --no-graph); counters per kernel family, "
                        "rocprofv3 --pmc, one pass per counter group (tools/pmc_step.sh)", "families": agg, "kernels": res},
               open(out, "w"), indent=1)
     for k, v in agg.items():

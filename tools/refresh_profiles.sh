@@ -1,7 +1,7 @@
 # Regenerates the evidence under gpurun_out/<tag>/ (run on the GPU box from the repo root); copy what is to be tracked
 # into profiles/ with the round prefix.   tag = $1 (default r02)
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
@@ -9,7 +9,7 @@ mkdir -p gpurun_out/$tag
 timeout -k 10 900 python bench.py > gpurun_out/$tag/bench_default.json 2> gpurun_out/$tag/bench_default.err
 tail -1 gpurun_out/$tag/bench_default.json | cut -c1-200
 # (2) kernel stats of the same command (no cpu leg under the profiler)
-(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/stats -o st -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/$tag/stats.log 2>&1)
+(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/stats -o st -- python3 $R/bench.py --no-cpu-baseline --no-instep > $R/gpurun_out/$tag/stats.log 2>&1)
 cp gpurun_out/$tag/stats/st_kernel_stats.csv gpurun_out/$tag/kernel_stats_bench_default.csv
 # (3) per-shape conv report + timeline of one replayed step
 timeout -k 10 600 python tools/conv_report.py > gpurun_out/$tag/conv_per_shape_report.txt 2>&1
