@@ -247,42 +247,72 @@ def instep_profile(model, timeout_s=240):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, deadline_s=None, child_cmd=None):
     """Launcher for `python bench.py --gpus N` without torch.distributed.run: one child per GPU with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1. Children are new processes (never a re-exec of one that
-    initialised the GPU). Returns the exit code: 0 only if every rank exited 0."""
+    initialised the GPU), each in a session of its own with a parent-death signal, so they cannot outlive the launcher:
+    SIGTERM / SIGINT to the launcher, a rank that dies, or the overall deadline (--timeout) stop exactly the child PIDs
+    (SIGTERM, then SIGKILL after a grace period). Returns the exit code: 0 only if every rank exited 0."""
+    import ctypes
+    import signal
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    import tempfile
+
+    def pdeathsig():      # child side, before exec: die with the launcher (PR_SET_PDEATHSIG = 1)
+        try:
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)
+        except Exception:  # noqa: BLE001
+            pass
     procs = []
     out0 = tempfile.TemporaryFile()
+    cmd = child_cmd or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
-    # a rank that dies leaves the others waiting in a collective: stop them (exact PIDs) instead of hanging
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL,
+                                      start_new_session=True, preexec_fn=pdeathsig))
     rcs = [None] * n
-    while any(rc is None for rc in rcs):
+    stop = {"why": None}
+
+    def on_signal(signum, _frame):
+        stop["why"] = "signal %d" % signum
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+
+    def stop_children():
         for r, p in enumerate(procs):
             if rcs[r] is None:
-                rcs[r] = p.poll()
-        if any(rc not in (None, 0) for rc in rcs):
+                p.terminate()
+        t_end = time.time() + 20
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                try:
+                    rcs[r] = p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    rcs[r] = p.wait()
+    t_start = time.time()
+    try:
+        # a rank that dies leaves the others waiting in a collective: stop them (exact PIDs) instead of hanging
+        while any(rc is None for rc in rcs):
             for r, p in enumerate(procs):
                 if rcs[r] is None:
-                    p.terminate()
-            for r, p in enumerate(procs):
-                if rcs[r] is None:
-                    try:
-                        rcs[r] = p.wait(timeout=20)
-                    except subprocess.TimeoutExpired:
-                        p.kill()
-                        rcs[r] = p.wait()
-            break
-        time.sleep(0.2)
+                    rcs[r] = p.poll()
+            if stop["why"] is None and deadline_s and time.time() - t_start > deadline_s:
+                stop["why"] = "deadline of %.0f s" % deadline_s
+            if stop["why"] is not None or any(rc not in (None, 0) for rc in rcs):
+                stop_children()
+                break
+            time.sleep(0.2)
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if stop["why"] is not None:
+        sys.stderr.write("bench.py: launcher stopped its ranks (%s)\n" % stop["why"])
+        return 124
     out0.seek(0)
     sys.stdout.write(out0.read().decode("utf-8", "replace"))
     sys.stdout.flush()
@@ -299,6 +329,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--timeout", type=float, default=0.0,
+                    help="--gpus N launcher only: overall deadline in seconds (0 = none); the ranks are stopped when it passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timer", action="store_true")
     ap.add_argument("--no-instep", action="store_true",
@@ -319,7 +351,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Plain `python bench.py --gpus N`: this process becomes a launcher. It starts N fresh rank processes BEFORE
         # anything here touches the GPU (no torch import yet), relays rank 0's JSON line and fails if any rank fails.
-        sys.exit(spawn_ranks(args.gpus))
+        sys.exit(spawn_ranks(args.gpus, args.timeout or None))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     instep = None

@@ -35,9 +35,12 @@ class FPNRoIExtractor:
             self.outs[(R, C)] = self.out
         self.prepared = None
         if prepare_gather:
-            ws = self.gather_ws.get(R)
+            # the workspace size depends on the roi count AND on the pyramid geometry (per-row roi lists): a portrait batch
+            # after a landscape one needs a larger one. Buffers are kept per key, never freed (a captured step may hold one)
+            key = (R,) + tuple(tuple(f.shape[:3]) for f in self.feats)
+            ws = self.gather_ws.get(key)
             if ws is None:
-                ws = self.gather_ws[R] = roi_align_backward_gather_workspace(self.feats, self.scales, R, self.lvl_min)
+                ws = self.gather_ws[key] = roi_align_backward_gather_workspace(self.feats, self.scales, R, self.lvl_min)
             roi_align_backward_gather_prepare(self.feats, self.scales, rois, self.levels, self.pooled, self.sr,
                                               self.lvl_min, ws)
             self.prepared = ws

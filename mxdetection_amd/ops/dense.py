@@ -12,13 +12,17 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
 def mem_range(*tensors):
-    """(ptr, bytes) of one tensor, or of the span of several when they sit next to each other (the filters of a
-    bottleneck's conv1 and projection shortcut are neighbours in the bf16 arena); else of the first."""
+    """(ptr, bytes) of one tensor, or of the span of several when they are views of ONE allocation (the filters of a
+    bottleneck's conv1 and projection shortcut are neighbours in the bf16 arena); else of the first. The kernels issue
+    real loads over the span (mxdet_conv_desc_t.prefetch): a gap between two separate allocations is not the caller's
+    memory and may not even be mapped, so separately allocated tensors are never spanned."""
     spans = [(t.data_ptr(), t.numel() * t.element_size()) for t in tensors]
-    lo = min(p for p, _ in spans)
-    hi = max(p + n for p, n in spans)
-    if hi - lo <= 2 * sum(n for _, n in set(spans)):
-        return (lo, hi - lo)
+    bases = {t.untyped_storage().data_ptr() for t in tensors}
+    if len(bases) == 1:
+        lo = min(p for p, _ in spans)
+        hi = max(p + n for p, n in spans)
+        if hi - lo <= 2 * sum(n for _, n in set(spans)):
+            return (lo, hi - lo)
     return spans[0]
 
 

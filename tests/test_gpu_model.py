@@ -45,6 +45,21 @@ def test_train_step_runs_and_is_deterministic(hip):
     assert g0.abs().sum().item() > 0
 
 
+def test_train_step_landscape_then_portrait_on_one_model(hip):
+    """Eager training over batches of two orientations (the loader's pad_to='orient' groups): the RoIAlign gather workspace
+    depends on the pyramid heights as well as on the roi count, so the portrait batch needs a larger one than the
+    landscape batch that ran first (it used to be cached by roi count alone and the second step raised EWORKSPACE)."""
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    m = FasterRCNN("cuda", seed=7, pre_nms_top_n=600, post_nms_top_n=300, rois_per_image=128)
+    for k, (H, W) in enumerate(((256, 448), (448, 256), (256, 448))):
+        image, gt, im_info = _inputs(2, H, W)
+        rpn, rcnn = m.train_step(image, gt, im_info, step=k, lr=0.001)
+        torch.cuda.synchronize()
+        vals = torch.cat([rpn, rcnn]).cpu().numpy()
+        assert np.all(np.isfinite(vals)) and vals[0] > 0, (H, W, vals)
+
+
 def test_detector_learns_a_fixed_batch(hip):
     """The detector can fit something: 400 replayed steps on ONE fixed 2-image batch (three objects painted into noise)
     drive the box-head classification loss below 0.2 and every RPN / box loss far below its start, and predict() then
