@@ -339,8 +339,6 @@ def main():
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the main stream")
     ap.add_argument("--no-branch-stream", action="store_true", help="keep the RPN training branch on the main stream")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="two launches per layer instead of per bucket")
-    ap.add_argument("--fused-backward", action="store_true",
-                    help="weight-gradient tiles ride in the data-gradient launches of the backward chain")
     ap.add_argument("--input", default="resident", choices=["resident", "loader"],
                     help="resident = batches already in HBM (the headline contract); loader = every step takes its batch from "
                          "datasets.DetectionLoader: host frames -> pinned -> H2D -> preprocess kernel (PCIe-inclusive rate)")
@@ -378,12 +376,6 @@ def main():
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
     from mxdetection_amd.models import FasterRCNN, RetinaNet
-    if os.environ.get("MXDET_WGRAD_CHUNK"):
-        from mxdetection_amd import _lib
-        _lib.load().mxdet_debug_wgrad_group_chunk(int(os.environ["MXDET_WGRAD_CHUNK"]))
-    if os.environ.get("MXDET_WGRAD_PERSIST"):
-        from mxdetection_amd import _lib
-        _lib.load().mxdet_debug_wgrad_group_persist(int(os.environ["MXDET_WGRAD_PERSIST"]))
     timer = ConvTimer()
     if not args.no_conv_timer:
         timer.install()
@@ -397,8 +389,6 @@ def main():
         model.enable_branch_stream()
     if not args.no_grouped_wgrad:
         model.enable_grouped_wgrad()
-    if args.fused_backward:
-        model.enable_fused_backward()
     if dist is not None:
         model.enable_data_parallel(world)
         model.broadcast_parameters(0)

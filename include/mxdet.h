@@ -419,19 +419,6 @@ int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wg
 int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
                                      int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
                                      size_t workspace_needed, mxdet_stream_t stream);
-/* Fused backward launch: the data-gradient tiles of a planned conv group (kind 1, tile cfg 2 or 3; table, cfg and
- * grid from mxdet_conv2d_grouped_plan) and the weight-gradient tiles [w_block_begin, w_block_end) of a planned wgrad
- * group in ONE grid, so that both kinds of workgroups share the CUs (small-map dgrad launches leave half the chip idle
- * and do not overlap with another stream's kernels). w_block_begin must be a multiple of 8; the caller issues a
- * group's remaining tiles and its fold with mxdet_conv2d_wgrad_grouped_from once every fused launch is enqueued. */
-int mxdet_fused_dgrad_wgrad(const void* conv_table_dev, int32_t cn, int32_t cfg, int32_t cgrid,
-                            const void* wgrad_table_dev, int32_t wn, int32_t w_block_begin, int32_t w_block_end,
-                            void* wgrad_workspace, mxdet_stream_t stream);
-/* block0_out[i] = first workgroup of item i of a planned wgrad group (host table), block0_out[n] = its grid */
-int mxdet_conv2d_wgrad_grouped_item_blocks(const void* table_host, int32_t n, int32_t* block0_out);
-int mxdet_conv2d_wgrad_grouped_from(const void* table_dev, int32_t n, int32_t block_begin, int32_t grid_wgrad,
-                                    int32_t grid_reduce, void* workspace, size_t workspace_bytes,
-                                    size_t workspace_needed, mxdet_stream_t stream);
 /* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);

@@ -16,10 +16,6 @@ extern "C" {
 int mxdet_debug_force_conv_cfg(int32_t cfg);
 /* force the split-K factor of mxdet_conv2d_wgrad on the calling thread (0 = heuristic) */
 int mxdet_debug_force_wgrad_ksplit(int32_t ksplit);
-/* issue a grouped weight-gradient launch in chunks of `workgroups` (0 = one launch); library-wide */
-int mxdet_debug_wgrad_group_chunk(int32_t workgroups);
-/* run grouped weight-gradient launches as a persistent grid of `workgroups` (rounded up to 8; 0 = off); library-wide */
-int mxdet_debug_wgrad_group_persist(int32_t workgroups);
 /* 1 = always use the direct-gather preprocess kernel (the wide-frame path); library-wide */
 int mxdet_debug_preprocess_direct(int32_t on);
 

@@ -140,11 +140,6 @@ SIGNATURES = {
     "mxdet_conv2d_wgrad_grouped_parts": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_debug_force_wgrad_ksplit": (c_i32, [c_i32]),
-    "mxdet_fused_dgrad_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "mxdet_conv2d_wgrad_grouped_item_blocks": (c_i32, [c_vp, c_i32, c_vp]),
-    "mxdet_conv2d_wgrad_grouped_from": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
-    "mxdet_debug_wgrad_group_chunk": (c_i32, [c_i32]),
-    "mxdet_debug_wgrad_group_persist": (c_i32, [c_i32]),
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mxdet_filter_transpose_batched": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "mxdet_stem_conv7x7": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
@@ -171,8 +166,8 @@ SIGNATURES = {
 }
 
 # entries declared in include/mxdet_debug.h (tuning / test hooks, not part of the drop-in boundary)
-DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_wgrad_group_chunk",
-                 "mxdet_debug_wgrad_group_persist", "mxdet_debug_preprocess_direct", "mxdet_debug_set_tuning")
+DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit", "mxdet_debug_preprocess_direct",
+                 "mxdet_debug_set_tuning")
 TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "T3_ENABLE": 6,
                "T3_TARGET": 7, "T3_MINSTEPS": 8, "T3_NS": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14,
                "T128W": 15, "T3_MIX": 16}

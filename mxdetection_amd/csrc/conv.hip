@@ -19,7 +19,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "wgrad_tile.h"
 
 namespace mxdet {
 
@@ -89,51 +88,34 @@ __device__ unsigned long long g_conv_stamp[2][8];
 // NS-1 stages (48-96 KiB per CU) are in flight and the global-load latency is off the critical path.
 // One counted s_waitcnt vmcnt + one raw s_barrier per K-step; the LDS image is lane-linear, so the
 // conflict-avoiding XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read side.
-// EXT_LDS: the caller (fused backward kernel) owns one LDS pool that this tile and the weight-gradient tile overlay.
-// KU = K-steps per barrier (1 or 2). KU = 2: a ring of NS >= 4 stages consumed two at a time -- one barrier, one exposed
-// LDS-read latency and one counted wait per 128 reduction elements instead of per 64; the second step's fragments are
-// read underneath the first step's MFMAs (both stages have landed at the barrier). For the small tiles, whose steps are
-// bound by that per-step chain (barrier -> fragment reads -> 8 MFMAs) at two waves per SIMD, not by MFMA or load rate.
 // TAPS = KH*KW when the caller guarantees a 1x1 (stride 1, pad 0) or a 3x3 (pad 1; stride 1, or any stride in the
 // forward direction) layer; 0 = any geometry, all bookkeeping at run time. With TAPS known the K loop is unrolled over the taps: the tap of every stage is a constant, its
 // displacement and filter column are loop-invariant scalars, and the ~50 dependent scalar instructions per step that
 // walked (kh, kw, channel slice) at run time disappear -- on the 64-row tiles, at 1-3 waves per SIMD, that serial
 // bookkeeping cost as many cycles per step as the step's eight MFMAs.
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, bool EXT_LDS = false, int KU = 1, int TAPS = 0,
-          int CHAIN = 0>
-__device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg,
-                                                unsigned char* lds_pool = nullptr) {
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int TAPS = 0, int CHAIN = 0>
+__device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const int nwg) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
-  // NS == 1 selects the half-stage pipeline (HP, see the main loop): two buffers whose 32-channel halves are refilled
-  // and consumed separately, fragments of the next half always read from LDS underneath the current half's MFMAs.
-  constexpr bool HP = (NS == 1);
-  constexpr int NBUF = HP ? 2 : NS;
-  constexpr int RPI = HP ? 16 : 8;                    // tile rows per LDS-DMA instruction (HP: 16 rows x 64 B)
-  constexpr int GA = BM / RPI / NW, GB = BN / RPI / NW;   // LDS-DMA instructions per wave per (half-)stage
+  constexpr int NBUF = NS;
+  constexpr int RPI = 8;                              // tile rows per LDS-DMA instruction (8 rows x 128 B)
+  constexpr int GA = BM / RPI / NW, GB = BN / RPI / NW;   // LDS-DMA instructions per wave per stage
   constexpr int STAGE = (BM + BN) * 64;               // bf16 elements per stage
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "rows must split evenly over the waves");
   static_assert(MT % 2 == 0, "epilogue stages two m-tiles at a time");
-  static_assert(HP || (NS >= 2 && (NS - 2) * (GA + GB) <= 63), "vmcnt is a 6-bit counter");
-  static_assert(KU == 1 || (KU == 2 && !HP && NS >= 4), "two steps per barrier need a ring of at least four stages");
-  static_assert(TAPS == 0 || ((TAPS == 1 || TAPS == 9) && !PAR && !HP && KU == 1), "static taps: plain ring, 1x1 or 3x3");
+  static_assert(NS >= 2 && (NS - 2) * (GA + GB) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(TAPS == 0 || ((TAPS == 1 || TAPS == 9) && !PAR), "static taps: 1x1 or 3x3");
   constexpr int EP_STRIDE = WTN + 4;
   constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
   constexpr int MAIN_BYTES = NBUF * STAGE * 2;
   // CHAIN > 0: a 1x1 convolution to CHAIN columns follows in the same workgroup (see after the K loop); its whole filter
   // (CHAIN x 64 bf16) sits behind the ring / epilogue area for the workgroup's life
-  static_assert(CHAIN == 0 || (TAPS == 9 && !DGRAD && WN == 1 && BN == 64 && CHAIN % (8 * NW) == 0 && !EXT_LDS),
+  static_assert(CHAIN == 0 || (TAPS == 9 && !DGRAD && WN == 1 && BN == 64 && CHAIN % (8 * NW) == 0),
                 "chain: forward 3x3 whose waves own all 64 mid channels of their rows");
   constexpr int CHAIN_OFF = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
   constexpr int SMEM_BYTES = CHAIN_OFF + CHAIN * 128;
-  unsigned char* smem_raw;
-  if constexpr (EXT_LDS) {
-    smem_raw = lds_pool;
-  } else {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem_own[SMEM_BYTES];
-    smem_raw = smem_own;
-  }
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
   uint16_t* smem = (uint16_t*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,9 +174,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   // The address math is hoisted out of the K loop (the loop was VALU-issue bound on it): per row a base
   // element offset and a bitmask of the taps that fall inside the image are computed once; inside the loop
   // a load costs one add + one bit test + one select, the per-tap displacement being a uniform SALU value.
-  // (HP: row 16j + (l>>2), 16-B slot l&3 of a 64-B half row; the swizzle uses two bits)
-  const int lrow = HP ? lane >> 2 : lane >> 3, lslot = HP ? lane & 3 : lane & 7;
-  constexpr int SWZ = HP ? 3 : 7;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  constexpr int SWZ = 7;
   // LDS-DMA in the buffer form (descriptor in SGPRs + 32-bit byte offset per lane): a fifth of the per-wave issue cost
   // of the 64-bit-address form (tools/micro/dma_rate.hip: 20 vs 116 cycles per 1-KiB piece), and a lane whose offset is
   // out of range writes zeros into its LDS slot by itself (padding taps need no zero page and no pointer select)
@@ -397,128 +378,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   MXDET_CS(1);
 
   const int frow = lane & 15, fq = lane >> 4;
-  if constexpr (HP) {
-    // ---- half-stage pipeline -------------------------------------------------------------------------------------
-    // Stage t lives in buffer t&1 as [A h0 | B h0 | A h1 | B h1] (h = 32-channel half, rows of 64 B). Step t:
-    //   barrier A: S(t)h1 landed everywhere, S(t)h0's fragments are in registers -> refill that region with S(t+2)h0;
-    //              MFMAs on S(t)h0 run while the fragments of S(t)h1 are read;
-    //   barrier B: S(t+1)h0 landed, S(t)h1's fragments are in registers -> refill with S(t+2)h1;
-    //              MFMAs on S(t)h1 run while the fragments of S(t+1)h0 are read.
-    // Every DMA has 1.5 steps to land, no fragment read is exposed behind a barrier (the plain ring reads the first
-    // half's fragments right after its barrier with the matrix pipes idle), LDS use equals the two-stage ring's.
-    constexpr int HALF = (BM + BN) * 32;            // bf16 elements per half-stage
-    constexpr int H = GA + GB;                      // DMA instructions per wave per half-stage
-    static_assert(3 * H <= 63, "vmcnt is a 6-bit counter");
-    auto issue_half = [&](int buf, int h) {
-      unsigned char* sbase = smem_raw + (size_t)buf * (STAGE * 2) + (size_t)h * (HALF * 2);
-      const bool live = ld_kt < KT;
-      int tap, delta, koff;
-      if constexpr (PAR) {
-        tap = live ? ld_kh * nkw + ld_kw : 31;
-        delta = ld_c0 - (ld_kh * p.Ws + ld_kw) * p.C;
-        koff = live ? ((par_ph + 2 * ld_kh) * p.KW + (par_pw + 2 * ld_kw)) * p.C + ld_c0 : 0;
-      } else {
-        tap = live ? ld_kh * p.KW + ld_kw : 31;
-        if (DGRAD) delta = ld_c0 - ((ld_kh / p.stride) * p.Ws + (ld_kw / p.stride)) * p.C;
-        else delta = ld_c0 + (ld_kh * p.Ws + ld_kw) * p.C;
-        koff = live ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;
-      }
-      delta += h * 32;
-      koff += live ? h * 32 : 0;
-#pragma unroll
-      for (int i = 0; i < GA; ++i) {
-        const unsigned vo = ((a_mask[i] >> tap) & 1u) ? 2u * (unsigned)(a_off[i] + delta) : kDmaOob;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(sbase + (wid * GA + i) * 1024), 16, (int)vo, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < GB; ++i) {
-        const unsigned wo = 2u * (unsigned)(wrow[i] + koff);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(sbase + BM * 64 + (wid * GB + i) * 1024), 16, (int)wo, 0, 0, 0);
-      }
-      if (h == 1) {
-        ++ld_kt;
-        if (++ld_kw == nkw) {
-          ld_kw = 0;
-          if (++ld_kh == nkh) { ld_kh = 0; ld_c0 += 64; }
-        }
-      }
-    };
-    // element offsets of this lane's fragment rows inside a half (fixed for the whole loop)
-    int fa[MT], fb[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int r = wm * WTM + i * 16 + frow;
-      fa[i] = r * 32 + ((fq ^ ((r >> 1) & 3)) << 3);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int r = wn * WTN + j * 16 + frow;
-      fb[j] = BM * 32 + r * 32 + ((fq ^ ((r >> 1) & 3)) << 3);
-    }
-    bf16x8_t x0a[MT], x0b[NT], x1a[MT], x1b[NT];
-    issue_half(0, 0);
-    issue_half(0, 1);
-    issue_half(1, 0);
-    issue_half(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * H) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < MT; ++i) x0a[i] = *(const bf16x8_t*)(smem + fa[i]);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) x0b[j] = *(const bf16x8_t*)(smem + fb[j]);
-    for (int kt = 0; kt < KT; ++kt) {
-      const int cur = kt & 1;
-      const uint16_t* s1 = smem + cur * STAGE + HALF;          // S(kt) second half
-      const uint16_t* s0n = smem + (cur ^ 1) * STAGE;          // S(kt+1) first half
-      // ---- phase 1 ----
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * H) : "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      issue_half(cur, 0);
-      __builtin_amdgcn_s_setprio(1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) x1a[i] = *(const bf16x8_t*)(s1 + fa[i]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) x1b[j] = *(const bf16x8_t*)(s1 + fb[j]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0a[i], x0b[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < MT + NT; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
-      // ---- phase 2 ----
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * H) : "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      issue_half(cur, 1);
-      __builtin_amdgcn_s_setprio(1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) x0a[i] = *(const bf16x8_t*)(s0n + fa[i]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) x0b[j] = *(const bf16x8_t*)(s0n + fb[j]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1a[i], x1b[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < MT + NT; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  } else if constexpr (TAPS > 0) {
+  if constexpr (TAPS > 0) {
   // ---- static taps: stride-1 1x1 / 3x3, everything per step that can be a constant is one --------------------------
   constexpr int TKW = TAPS == 9 ? 3 : 1;
   constexpr int SL = (NS % TAPS == 0 || TAPS % NS == 0) ? (TAPS % NS == 0 ? 1 : NS) : NS;   // slices per unrolled block
@@ -636,75 +496,6 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         __builtin_amdgcn_s_setprio(0);
       }
     }
-  }
-  } else if constexpr (KU == 2) {
-#pragma unroll
-  for (int s0 = 0; s0 < NS - 2; ++s0) issue_stage(s0);
-  int cur = 0, nxt = NS - 2;
-  const int KT2 = (KT + 1) >> 1;           // an odd tail multiplies one all-zero stage (its loads were out of range)
-  for (int it = 0; it < KT2; ++it) {
-    // both stages of this iteration have landed once all but the (NS-4) youngest stages' loads of this wave are done
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 4) * (GA + GB)) : "memory");
-    __builtin_amdgcn_s_barrier();          // ... in every wave; and every wave is done with the two buffers refilled next
-    asm volatile("" ::: "memory");
-    const int cur1 = (cur + 1 == NS) ? 0 : cur + 1;
-    const uint16_t* sa0 = smem + cur * STAGE;
-    const uint16_t* sb0 = sa0 + BM * 64;
-    const uint16_t* sa1 = smem + cur1 * STAGE;
-    const uint16_t* sb1 = sa1 + BM * 64;
-    bf16x8_t a00[MT], b00[NT], a01[MT], b01[NT], a10[MT], b10[NT], a11[MT], b11[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a00[i] = *(const bf16x8_t*)(sa0 + lds_off(wm * WTM + i * 16 + frow, fq));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b00[j] = *(const bf16x8_t*)(sb0 + lds_off(wn * WTN + j * 16 + frow, fq));
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a01[i] = *(const bf16x8_t*)(sa0 + lds_off(wm * WTM + i * 16 + frow, 4 + fq));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b01[j] = *(const bf16x8_t*)(sb0 + lds_off(wn * WTN + j * 16 + frow, 4 + fq));
-    __builtin_amdgcn_sched_barrier(0);
-    issue_stage(nxt);
-    issue_stage((nxt + 1 == NS) ? 0 : nxt + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a10[i] = *(const bf16x8_t*)(sa1 + lds_off(wm * WTM + i * 16 + frow, fq));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b10[j] = *(const bf16x8_t*)(sb1 + lds_off(wn * WTN + j * 16 + frow, fq));
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a11[i] = *(const bf16x8_t*)(sa1 + lds_off(wm * WTM + i * 16 + frow, 4 + fq));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b11[j] = *(const bf16x8_t*)(sb1 + lds_off(wn * WTN + j * 16 + frow, 4 + fq));
-    __builtin_amdgcn_s_setprio(1);
-#ifndef MXDET_ABL_NOMFMA
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00[i], b00[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01[i], b01[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10[i], b10[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11[i], b11[j], acc[i][j], 0, 0, 0);
-#else
-#pragma unroll
-    for (int i = 0; i < MT; ++i) { asm volatile("" ::"v"(a00[i]), "v"(a01[i]), "v"(a10[i]), "v"(a11[i])); }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { asm volatile("" ::"v"(b00[j]), "v"(b01[j]), "v"(b10[j]), "v"(b11[j])); }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(0);
-    cur = (cur1 + 1 == NS) ? 0 : cur1 + 1;
-    nxt = (nxt + 2 >= NS) ? nxt + 2 - NS : nxt + 2;
   }
   } else {
 #pragma unroll
@@ -1051,328 +842,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
 #endif
 }
 
-// ---- 3x3 / stride 1 / pad 1 with TAP REUSE (forward and data gradient) --------------------------------------------------
-// The static-tap loop above is, on the 64-row tiles, bound by the CU's vector-memory path: 64 B/clk move 16 KiB per
-// step while the step's MFMAs need half of those cycles. The three taps (kh, 0..2) of a 3x3 read the SAME pixels shifted
-// by one: here the gathered operand of a (channel slice, kh) is loaded ONCE as a super-tile of BM + 2 consecutive pixels
-// (BM + 8 rows of 128 B, 8 rows per LDS-DMA piece) and tap kw multiplies rows kw .. kw + BM - 1 of it. Rows whose tap
-// falls off the map (the linear shift wraps to the neighbouring row / image there) are zeroed in the FRAGMENT registers
-// (a per-lane 9-bit tap mask, four v_cndmask per fragment half). Bytes per three taps: (BM + 8 + 3 BN) x 128 instead of
-// 3 (BM + BN) x 128 -- 41 KiB for 3.1 MFLOP at 128 x 64, which the MFMAs, not the memory path, bound.
-//   LDS: gathered super-tile double-buffered (stage = (slice, kh)), filter tiles a ring of three single taps.
-//   Step t (one tap): wait + barrier; fragment reads; issue the filter tile of tap t+2 and, at kw = 0, the super-tile of
-//   the next (slice, kh); masks; 2 x MT x NT MFMAs. Piece counts differ by wave (wave 0 takes the odd super-tile piece):
-//   the counted vmcnt of each unrolled step is chosen per wave.
-template <int BM, int BN, int WM, int WN, bool DGRAD>
-__device__ __forceinline__ void conv3x3_tr_tile(const ConvP& p, int bid, const int nwg) {
-  constexpr int NW = WM * WN;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MT = WTM / 16, NT = WTN / 16;
-  constexpr int AROWS = BM + 8, AP = AROWS / 8;           // super-tile rows / pieces
-  constexpr int APW = (AP + NW - 1) / NW;                 // most pieces a wave takes (waves < AP % NW take one more than the rest)
-  constexpr int APLO = AP / NW;                           // fewest
-  constexpr int ABYTES = AROWS * 128, BBYTES = BN * 128;
-  constexpr int BPW = BN / 8 / NW;                        // filter pieces per wave per tap
-  static_assert(BN % (8 * NW) == 0 && MT % 2 == 0, "tile shape");
-  constexpr int EP_STRIDE = WTN + 4;
-  constexpr int EP_BYTES = NW * 32 * EP_STRIDE * 4;
-  constexpr int MAIN_BYTES = 2 * ABYTES + 3 * BBYTES;
-  constexpr int SMEM_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
-  uint16_t* smem = (uint16_t*)smem_raw;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-  const int m0 = p.m_begin + tile_m * BM;
-  const int n0 = tile_n * BN;
-  const int W = p.Wd, H = p.Hd, C = p.C;                  // stride 1, pad 1: source and destination maps coincide
-  const int lrow = lane >> 3, lslot = lane & 7;
-  const int frow = lane & 15, fq = lane >> 4;
-  const int Ktot = 9 * C;
-  const int nslices = C >> 6;
-
-  // ---- filter pieces: wave w, piece k covers filter rows 8 (w BPW + k) .. +7 of the tile -------------------------------
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.w, 2u * (unsigned)p.Ncols * (unsigned)Ktot);
-  unsigned vob[BPW];
-#pragma unroll
-  for (int k = 0; k < BPW; ++k) {
-    const int rb = (wid * BPW + k) * 8 + lrow;
-    int n = n0 + rb;
-    n = n < p.Ncols ? n : p.Ncols - 1;
-    vob[k] = 2u * (unsigned)(n * Ktot + ((lslot ^ ((rb >> 1) & 7)) << 3));
-  }
-  auto issue_b = [&](int slot, int tap, int c0, bool live) {            // slot, tap: constants after unrolling
-    const int so = live ? 2 * (tap * C + c0) : 0;
-#pragma unroll
-    for (int k = 0; k < BPW; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem_raw + 2 * ABYTES + slot * BBYTES + (wid * BPW + k) * 1024),
-                                               16, (int)vob[k], so, 0, 0);
-  };
-  // the first two filter tiles go out before the geometry (cold weights land underneath it)
-  issue_b(0, 0, 0, true);
-  issue_b(1, 1, 0, true);
-
-  // ---- super-tile pieces: wave w takes pieces w, w + NW, ... ; lane -> row 8 piece + lrow ------------------------------
-  // Row r of the super-tile of stage (slice, kh) is the source pixel m0 - 1 + r + (kh - 1) W (forward) or
-  // m0 - 1 + r + (1 - kh) W (data gradient, whose tap kw reads row j + 2 - kw). The descriptor starts (W + 1) pixels
-  // before the tensor: the per-lane offset (m0 + r) C is then non-negative and the stage's uniform part
-  // (kh W C + slice, or (2 - kh) W C + slice) rides in the scalar offset. A lane whose pixel lies outside the tensor loads nothing.
-  const int bias_el = (W + 1) * C;
-  const __amdgpu_buffer_rsrc_t rsrc_xs = make_rsrc(p.x - bias_el, 2u * (unsigned)p.M * (unsigned)C + 2u * (unsigned)bias_el);
-  unsigned voa[APW];
-  unsigned aval[APW];                                      // bit kh: this row's pixel of stage kh is inside the tensor
-#pragma unroll
-  for (int k = 0; k < APW; ++k) {
-    const int piece = wid + k * NW;
-    const int r = piece * 8 + lrow;
-    voa[k] = 2u * (unsigned)((m0 + r) * C + ((lslot ^ ((r >> 1) & 7)) << 3));
-    unsigned v = 0;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int s = m0 - 1 + r + (DGRAD ? 1 - kh : kh - 1) * W;
-      if (piece < AP && s >= 0 && s < p.M) v |= 1u << kh;
-    }
-    aval[k] = v;
-  }
-  auto issue_a = [&](int buf, int kh, int c0, bool live) {              // buf, kh: constants after unrolling
-    const int so = live ? 2 * ((DGRAD ? 2 - kh : kh) * W * C + c0) : 0;
-#pragma unroll
-    for (int k = 0; k < APW; ++k) {
-      if (k == APW - 1 && APW != APLO && wid >= AP % NW) break;        // wave-uniform: this wave has one piece fewer
-      const unsigned vo = (live && ((aval[k] >> kh) & 1u)) ? voa[k] : kDmaOob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xs, (lptr_t)(smem_raw + buf * ABYTES + (wid + k * NW) * 1024), 16, (int)vo,
-                                               so, 0, 0);
-    }
-  };
-
-  // ---- per-lane tap masks of the fragment rows ---------------------------------------------------------------------------
-  unsigned tmask[MT];
-  {
-    const int hw = H * W;
-    const float rcp_hw = 1.0f / (float)hw, rcp_w = 1.0f / (float)W;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + frow;
-      unsigned mk = 0;
-      if (m < p.M) {
-        int rem, w;
-        (void)fast_divmod(m, hw, rcp_hw, &rem);
-        const int h = fast_divmod(rem, W, rcp_w, &w);
-        // forward: tap (kh, kw) reads (h + kh - 1, w + kw - 1); data gradient: (h + 1 - kh, w + 1 - kw)
-        const unsigned up = h >= 1 ? 1u : 0u, dn = h + 1 < H ? 1u : 0u, lf = w >= 1 ? 1u : 0u, rt = w + 1 < W ? 1u : 0u;
-        const unsigned rowm = DGRAD ? (dn | 2u | (up << 2)) : (up | 2u | (dn << 2));
-        const unsigned colm = DGRAD ? (rt | 2u | (lf << 2)) : (lf | 2u | (rt << 2));
-        mk = ((rowm & 1u) ? colm : 0u) | (colm << 3) | ((rowm & 4u) ? colm << 6 : 0u);
-      }
-      tmask[i] = mk;
-    }
-  }
-  issue_a(0, 0, 0, true);
-
-  // fragment addresses (elements): row j + shift of the super-tile, shift = kw (forward) / 2 - kw (data gradient)
-  int fa[3][2];
-#pragma unroll
-  for (int sh = 0; sh < 3; ++sh) {
-    fa[sh][0] = lds_off(wm * WTM + frow + sh, fq);
-    fa[sh][1] = lds_off(wm * WTM + frow + sh, 4 + fq);
-  }
-  const int fb0 = lds_off(wn * WTN + frow, fq), fb1 = lds_off(wn * WTN + frow, 4 + fq);
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the prologue's pieces (the first super-tile went out last)
-  // Issue order of a wave: [B0 B1] [A0] | step 0: [A1] [B2] | step 1: [B3] | step 2: [B4] | step 3: [A2] [B5] | ...
-  // Step t needs B_t (and, at kw = 0, the super-tile issued three steps earlier, which precedes B_t): everything issued
-  // after B_t may still be in flight = B_{t+1}, plus the super-tile issued in the previous step when that one had kw = 0.
-  for (int cs = 0; cs < nslices; cs += 2) {
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      if (cs + sl >= nslices) break;                       // wave-uniform (odd slice count)
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int kh = tp / 3, kw = tp % 3;                // constants after unrolling
-        const int stage = sl * 3 + kh;                     // parity = super-tile buffer
-        const int t9 = sl * 9 + tp;                        // filter ring slot = t9 % 3
-        if (kw == 1) {
-          if (wid < AP % NW || APW == APLO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + APW) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + APLO) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const uint16_t* sa = smem + (stage & 1) * (ABYTES / 2);
-        const uint16_t* sb = smem + ABYTES + (t9 % 3) * (BBYTES / 2);
-        const int sh = DGRAD ? 2 - kw : kw;
-        bf16x8_t af0[MT], af1[MT], bf0[NT], bf1[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af0[i] = *(const bf16x8_t*)(sa + fa[sh][0] + i * 1024);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf0[j] = *(const bf16x8_t*)(sb + fb0 + j * 1024);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af1[i] = *(const bf16x8_t*)(sa + fa[sh][1] + i * 1024);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf1[j] = *(const bf16x8_t*)(sb + fb1 + j * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kw == 0) {                                     // the super-tile of the next (slice, kh)
-          const int nst = stage + 1;                       // its buffer: (stage + 1) & 1
-          const int nkh = (kh + 1) % 3, nslice = cs + sl + (kh + 1) / 3;
-          issue_a(nst & 1, nkh, nslice * 64, nslice < nslices);
-        }
-        {
-          const int nt = tp + 2;                           // filter tile two taps ahead
-          const int ntap = nt % 9, nslice = cs + sl + nt / 9;
-          issue_b((t9 + 2) % 3, ntap, nslice * 64, nslice < nslices);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // rows whose tap falls off the map multiply zeros
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const bool ok = (tmask[i] >> tp) & 1u;
-          u32x4_t a0 = __builtin_bit_cast(u32x4_t, af0[i]), a1 = __builtin_bit_cast(u32x4_t, af1[i]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { a0[e] = ok ? a0[e] : 0u; a1[e] = ok ? a1[e] : 0u; }
-          af0[i] = __builtin_bit_cast(bf16x8_t, a0);
-          af1[i] = __builtin_bit_cast(bf16x8_t, a1);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail loads before LDS is re-used
-  __syncthreads();
-
-  // ---- epilogue (as conv_igemm_tile, plain rows) ---------------------------------------------------------------------------
-  float* ep = (float*)smem_raw + wid * 32 * EP_STRIDE;
-  constexpr int LPR = WTN / 8;
-  constexpr int RPP = 64 / LPR;
-  constexpr int PASSES = 32 / RPP;
-  const int rl = lane / LPR, cg = lane - rl * LPR;
-  const int col = n0 + wn * WTN + cg * 8;
-  const bool colok = col < p.Ncols;
-  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-  if (p.bias) {
-    const int cb = colok ? col : 0;
-    b0 = *(const float4*)(p.bias + cb);
-    b1 = *(const float4*)(p.bias + cb + 4);
-  }
-#pragma unroll
-  for (int h = 0; h < MT / 2; ++h) {
-    size_t pixs[PASSES];
-    bool oks[PASSES];
-    uint4 rres[PASSES], rmsk[PASSES];
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int row = ps * RPP + rl;
-      const int m = m0 + wm * WTM + h * 32 + row;
-      oks[ps] = m < p.M && colok;
-      pixs[ps] = oks[ps] ? (size_t)m : 0;
-    }
-    if (p.res) {
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        size_t ri = pixs[ps] * p.Ncols + (oks[ps] ? col : 0);
-        if (p.res_up) {
-          const int m = (int)pixs[ps];
-          int img = m / (p.Hd * p.Wd);
-          int rem = m - img * (p.Hd * p.Wd);
-          int hd = rem / p.Wd, wd = rem - hd * p.Wd;
-          int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
-          ri = ((size_t)(img * Hc + (hd >> 1)) * Wc + (wd >> 1)) * p.Ncols + (oks[ps] ? col : 0);
-        }
-        rres[ps] = *(const uint4*)(p.res + ri);
-      }
-    }
-    if (p.mask) {
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps)
-        rmsk[ps] = *(const uint4*)(p.mask + pixs[ps] * p.Ncols + (oks[ps] ? col : 0));
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ep[(t * 16 + fq * 4 + r) * EP_STRIDE + j * 16 + frow] = acc[2 * h + t][j][r];
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int row = ps * RPP + rl;
-      float4 v0 = *(const float4*)(ep + row * EP_STRIDE + cg * 8);
-      float4 v1 = *(const float4*)(ep + row * EP_STRIDE + cg * 8 + 4);
-      float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
-      if (p.res) {
-        const uint4 rv = rres[ps];
-        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-        v[4] += __uint_as_float(rv.z << 16); v[5] += __uint_as_float(rv.z & 0xffff0000u);
-        v[6] += __uint_as_float(rv.w << 16); v[7] += __uint_as_float(rv.w & 0xffff0000u);
-      }
-      if (p.mask) {
-        const unsigned mm[4] = {rmsk[ps].x, rmsk[ps].y, rmsk[ps].z, rmsk[ps].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          unsigned lo = mm[k] & 0xffffu, hi = mm[k] >> 16;
-          if (!(lo != 0u && lo < 0x8000u)) v[2 * k] = 0.0f;
-          if (!(hi != 0u && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
-        }
-      }
-      if (p.relu && !p.mask) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
-      }
-      uint4 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      o.z = pack_bf16x2(v[4], v[5]);
-      o.w = pack_bf16x2(v[6], v[7]);
-      if (oks[ps]) *(uint4*)(p.y + pixs[ps] * p.Ncols + col) = o;
-    }
-  }
-}
-
-template <int BM, int BN, int WM, int WN, bool DGRAD>
-__global__ void __launch_bounds__(64 * WM * WN)
-conv3x3_tr_kernel(ConvP p) {
-  conv3x3_tr_tile<BM, BN, WM, WN, DGRAD>(p, (int)blockIdx.x, (int)gridDim.x);
-}
-
-template <int BM, int BN, int WM, int WN, bool DGRAD>
-static int launch_tr(ConvP& p, hipStream_t s) {
-  if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);
-  p.tiles_n = ceil_div(p.Ncols, BN);
-  const long long nwg = (long long)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv3x3_tr_kernel<BM, BN, WM, WN, DGRAD>), dim3((unsigned)nwg), dim3(64 * WM * WN), 0, s, p);
-  return check_launch("conv2d");
-}
-
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0, int CHAIN = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int TAPS = 0, int CHAIN = 0>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
-  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR, false, KU, TAPS, CHAIN>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR, TAPS, CHAIN>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped form: independent convolutions that share one tile configuration (the 3x3 of every pyramid level of an RPN
@@ -1397,49 +870,7 @@ conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
   const int nb = table[lo].nblocks;
   if (b >= nb) return;                      // alignment padding between items
   const ConvP p = table[lo].p;
-  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false, false, 1, TAPS>(p, b, nb);
-}
-
-// Fused backward launch: the data-gradient tiles of a layer (grouped-table form, blocks [0, cgrid)) and a slice of the
-// bucket's weight-gradient tiles (blocks [w_off, w_off + gridDim.x - cgrid_pad) of the grouped wgrad table) in ONE grid.
-// A dgrad launch of a C4/C5-sized layer is 264-528 workgroups, about one per CU, and streams do not overlap it with
-// the weight-gradient stream: here both kinds of workgroups are resident together by
-// construction. cgrid_pad and w_off are multiples of 8 so that every weight-gradient tile keeps its XCD.
-template <int BM, int BN, int WM, int WN, int NS>
-__global__ void __launch_bounds__(256)
-fused_bwd_kernel(const ConvG* __restrict__ ctable, int cn, int cgrid, int cgrid_pad, const WgradG* __restrict__ wtable,
-                 int wn, int w_off, unsigned char* __restrict__ wws) {
-  // one LDS pool, overlaid by the two tile kinds (a workgroup runs exactly one of them)
-  constexpr int CONV_EP = 4 * 32 * (BN / WN + 4) * 4, CONV_MAIN = NS * (BM + BN) * 64 * 2;
-  constexpr int CONV_LDS = CONV_MAIN > CONV_EP ? CONV_MAIN : CONV_EP, WG_LDS = 2 * 2 * kWgradBKP * 256;
-  __shared__ __attribute__((aligned(1024))) unsigned char pool[CONV_LDS > WG_LDS ? CONV_LDS : WG_LDS];
-  const int bid = (int)blockIdx.x;
-  if (bid < cgrid_pad) {
-    if (bid >= cgrid) return;
-    int lo = 0, hi = cn - 1;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) >> 1;
-      if (ctable[mid].block0 <= bid) lo = mid; else hi = mid - 1;
-    }
-    const int b = bid - ctable[lo].block0;
-    const int nb = ctable[lo].nblocks;
-    if (b >= nb) return;
-    const ConvP p = ctable[lo].p;
-    conv_igemm_tile<BM, BN, WM, WN, NS, true, false, true>(p, b, nb, pool);
-    return;
-  }
-  const int wb = bid - cgrid_pad + w_off;
-  int lo = 0, hi = wn - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (wtable[mid].block0 <= wb) lo = mid; else hi = mid - 1;
-  }
-  const int b = wb - wtable[lo].block0;
-  if (b >= wtable[lo].nblocks) return;
-  WgradP p = wtable[lo].p;
-  p.slab = (float*)(wws + (size_t)p.slab);
-  p.bslab = (float*)(wws + (size_t)p.bslab);
-  wgrad_tile<kWgradBKP, 2, true>(p, b, pool);
+  conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false, TAPS>(p, b, nb);
 }
 
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
@@ -1450,7 +881,7 @@ static int thr_t64() { return (int)tuning(MXDET_TUNE_T64); }
 static int thr_t128() { return (int)tuning(MXDET_TUNE_T128); }
 static int thr_par64() { return (int)tuning(MXDET_TUNE_PAR64); }
 
-template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int KU = 1, int TAPS = 0, int CHAIN = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, int TAPS = 0, int CHAIN = 0>
 static int launch_cfg(ConvP& p, hipStream_t s) {
   if (PAR) {   // rows grouped by parity class: tiles never straddle two classes
     int t = 0;
@@ -1465,7 +896,7 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
   if (TAPS == 1 && p.ksplit > 1) nwg *= p.ksplit;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, KU, TAPS, CHAIN>), dim3((unsigned)nwg),
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, TAPS, CHAIN>), dim3((unsigned)nwg),
                      dim3(64 * WM * WN), 0, s, p);
   return check_launch("conv2d");
 }
@@ -1473,82 +904,39 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
 // Tile choice (measured on MI355X, tools/bench_one_conv.py sweeps, profiles/r01_conv_cfg_sweep.txt): what matters
 // most is having 2-3 workgroups resident per CU so that one workgroup's barrier / LDS-latency / DMA-issue phases
 // overlap another's MFMA phase; a 2-stage ring (48-64 KiB of LDS) allows that, deeper rings do not pay.
-// the tap-reuse kernel's geometry: 3x3, stride 1, pad 1, maps at least 8 wide, whole 64-channel slices
-static bool tr_ok(const ConvP& p) {
-  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Wd >= 8 && p.C % 64 == 0 && p.m_begin == 0 &&
-         p.Hd == p.Hs && p.Wd == p.Ws;
-}
-
 template <bool DGRAD>
 static int launch(ConvP& p, hipStream_t s) {
   const int force = g_force_cfg;
   const long long t128 = (long long)ceil_div(p.M, 128) * ceil_div(p.Ncols, 128);
   const long long t64 = (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 128);
   const int K = p.KH * p.KW * p.C;
+  // forced tile configurations (mxdet_debug_force_conv_cfg: tools/sweep_cfg_all.py, tools/check_cfg.py). 3..8, 15: the
+  // run-time-geometry loop; 40..49: the static-tap loop (the caller passes a stride-1 1x1 / 3x3 layer)
+#define MXDET_FORCE_ST(BM, BN, WM, WN, NS)                                                  \
+  (p.KH * p.KW == 1 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1>(p, s) : launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 9>(p, s))
   switch (force) {
-    case 1: return launch_cfg<256, 64, 4, 1, 3, DGRAD>(p, s);
-    case 2: return launch_cfg<256, 128, 4, 2, 3, DGRAD>(p, s);
     case 3: return launch_cfg<128, 128, 2, 2, 4, DGRAD>(p, s);
-    case 4: return launch_cfg<64, 128, 2, 2, 4, DGRAD>(p, s);
     case 5: return launch_cfg<64, 64, 2, 2, 3, DGRAD>(p, s);
     case 6: return launch_cfg<64, 128, 2, 2, 2, DGRAD>(p, s);
     case 7: return launch_cfg<128, 128, 2, 2, 2, DGRAD>(p, s);
     case 8: return launch_cfg<128, 64, 4, 1, 2, DGRAD>(p, s);
-    case 10: return launch_cfg<64, 128, 2, 4, 2, DGRAD>(p, s);    // 8 waves, 32x32 per wave
-    case 11: return launch_cfg<128, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 32x64 per wave
-    case 12: return launch_cfg<64, 64, 2, 2, 2, DGRAD>(p, s);     // 32 KiB LDS: 5 workgroups per CU
-    case 13: return launch_cfg<128, 128, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 64x32 per wave
-    case 14: return launch_cfg<64, 128, 2, 2, 3, DGRAD>(p, s);    // 72 KiB: two workgroups per CU, prefetch distance 2
     case 15: return launch_cfg<256, 256, 2, 4, 2, DGRAD>(p, s);   // 8 waves, 128x64 per wave, 128 KiB
-    case 16: return launch_cfg<256, 128, 4, 2, 2, DGRAD>(p, s);   // 8 waves, 64x64 per wave, 96 KiB
-    case 17: return launch_cfg<256, 128, 2, 2, 2, DGRAD>(p, s);   // 4 waves, 128x64 per wave, 96 KiB
-    case 18: return launch_cfg<64, 64, 2, 2, 5, DGRAD>(p, s);     // 80 KiB: deep ring for grids of <= 2 workgroups per CU
-    case 19: return launch_cfg<64, 64, 2, 2, 4, DGRAD>(p, s);     // 64 KiB
-    case 26: return launch_cfg<64, 128, 2, 2, 5, DGRAD>(p, s);    // 120 KiB: one workgroup per CU, four stages in flight
-    // two K-steps per barrier (KU = 2)
-    case 30: return launch_cfg<64, 64, 2, 2, 4, DGRAD, false, 2>(p, s);    // 64 KiB
-    case 31: return launch_cfg<64, 128, 2, 2, 4, DGRAD, false, 2>(p, s);   // 96 KiB
-    case 32: return launch_cfg<64, 64, 2, 2, 6, DGRAD, false, 2>(p, s);    // 96 KiB, four stages in flight
-    case 33: return launch_cfg<128, 64, 4, 1, 4, DGRAD, false, 2>(p, s);   // 96 KiB
-    case 34: return launch_cfg<128, 128, 2, 2, 4, DGRAD, false, 2>(p, s);  // 128 KiB
-    // static taps (the caller of these test cases passes a matching stride-1 layer)
-    case 40: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 3, DGRAD, false, 1, 9>(p, s);
-    case 42: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 4, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 4, DGRAD, false, 1, 9>(p, s);
-    case 43: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 5, DGRAD, false, 1, 9>(p, s);
-    case 44: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 3, DGRAD, false, 1, 9>(p, s);
-    case 45: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
-    case 46: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 1, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 1, 2, DGRAD, false, 1, 9>(p, s);
-    case 47: if (p.KH * p.KW == 1) return launch_cfg<256, 64, 4, 1, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<256, 64, 4, 1, 2, DGRAD, false, 1, 9>(p, s);
-    case 48: if (p.KH * p.KW == 1) return launch_cfg<256, 128, 4, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<256, 128, 4, 2, 2, DGRAD, false, 1, 9>(p, s);
-    case 49: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 4, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 4, 2, DGRAD, false, 1, 9>(p, s);
-    case 60: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 2, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 2, 3, DGRAD, false, 1, 9>(p, s);
-    case 61: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 2, 4, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 2, 4, DGRAD, false, 1, 9>(p, s);
-    case 62: if (p.KH * p.KW == 1) return launch_cfg<128, 128, 2, 4, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 128, 2, 4, 3, DGRAD, false, 1, 9>(p, s);
-    case 63: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 4, 3, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 4, 3, DGRAD, false, 1, 9>(p, s);
-    case 64: if (p.KH * p.KW == 1) return launch_cfg<64, 64, 2, 2, 6, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 64, 2, 2, 6, DGRAD, false, 1, 9>(p, s);
-    case 65: if (p.KH * p.KW == 1) return launch_cfg<128, 64, 4, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<128, 64, 4, 2, 2, DGRAD, false, 1, 9>(p, s);
-    case 50: if (tr_ok(p)) return launch_tr<128, 64, 4, 1, DGRAD>(p, s); break;   // other layers: the heuristic
-    case 51: if (tr_ok(p)) return launch_tr<64, 64, 2, 2, DGRAD>(p, s); break;
-    case 52: if (tr_ok(p)) return launch_tr<128, 64, 4, 2, DGRAD>(p, s); break;   // 8 waves, 32 x 32 per wave
-    case 53: if (tr_ok(p)) return launch_tr<128, 128, 4, 2, DGRAD>(p, s); break;  // 8 waves, 32 x 64 per wave, 84 KiB
-    case 41: if (p.KH * p.KW == 1) return launch_cfg<64, 128, 2, 2, 2, DGRAD, false, 1, 1>(p, s); else return launch_cfg<64, 128, 2, 2, 2, DGRAD, false, 1, 9>(p, s);
-    // half-stage pipeline (NS = 1) variants
-    case 20: return launch_cfg<64, 64, 2, 2, 1, DGRAD>(p, s);
-    case 21: return launch_cfg<64, 128, 2, 2, 1, DGRAD>(p, s);
-    case 22: return launch_cfg<128, 128, 2, 2, 1, DGRAD>(p, s);
-    case 23: return launch_cfg<128, 64, 4, 1, 1, DGRAD>(p, s);
-    case 24: return launch_cfg<256, 256, 2, 4, 1, DGRAD>(p, s);
-    case 25: return launch_cfg<256, 128, 4, 2, 1, DGRAD>(p, s);
+    case 40: return MXDET_FORCE_ST(64, 64, 2, 2, 3);
+    case 41: return MXDET_FORCE_ST(64, 128, 2, 2, 2);
+    case 45: return MXDET_FORCE_ST(128, 128, 2, 2, 2);
+    case 46: return MXDET_FORCE_ST(128, 64, 4, 1, 2);
+    case 49: return MXDET_FORCE_ST(128, 128, 2, 4, 2);            // 8 waves, 64x32 per wave
     default: break;
   }
+#undef MXDET_FORCE_ST
   // stride-1 1x1 / 3x3 layers (all but the four stride-2 convolutions and the stem): the unrolled static-tap K loop
   const int taps = p.KH * p.KW;
   // (a forward 3x3 may be strided: its tap displacements do not depend on the stride; a strided data gradient may not)
   const int st = ((p.stride != 1 && (DGRAD || taps == 1)) || tuning(MXDET_TUNE_STATIC_TAPS) == 0) ? 0
                  : (taps == 1 && p.pad == 0) ? 1 : (p.KH == 3 && p.KW == 3 && p.pad == 1) ? 9 : 0;
 #define MXDET_LAUNCH_ST(BM, BN, WM, WN, NS)                                                        \
-  (st == 1 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1, 1>(p, s)                              \
-           : st == 9 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1, 9>(p, s)                    \
+  (st == 1 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1>(p, s)                                 \
+           : st == 9 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 9>(p, s)                       \
                      : launch_cfg<BM, BN, WM, WN, NS, DGRAD>(p, s))
   if constexpr (DGRAD) {
     if (p.stride == 2 && force == 0) {
@@ -1687,7 +1075,7 @@ extern "C" int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t
                   cout3);
     p.chain3_w = w3; p.chain3_bias = bias3; p.chain3_y = y3; p.chain3_relu = relu3;
   }
-  return launch_cfg<128, 64, 4, 1, 2, false, false, 1, 9, 256>(p, as_stream(stream));
+  return launch_cfg<128, 64, 4, 1, 2, false, false, 9, 256>(p, as_stream(stream));
 }
 
 // ---- split-K forward for long reductions on few rows (FC6: 1,024 rois x 12,544 features x 1,024 outputs) ----------------
@@ -1762,7 +1150,7 @@ extern "C" int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_
   const long long tiles = (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 64);
   MXDET_REQUIRE(tiles % 8 == 0, MXDET_ESHAPE, "conv2d_fwd_splitk: the tile count (%lld) must be a multiple of 8", tiles);
   hipStream_t s = as_stream(stream);
-  rc = launch_cfg<64, 64, 2, 2, 3, false, false, 1, 1>(p, s);
+  rc = launch_cfg<64, 64, 2, 2, 3, false, false, 1>(p, s);
   if (rc) return rc;
   const long long total = (long long)p.M * p.Ncols;
   hipLaunchKernelGGL(conv_splitk_fold_kernel, dim3((unsigned)ceil_div<long long>(total / 8, 256)), dim3(256), 0, s,
@@ -1915,26 +1303,4 @@ extern "C" int mxdet_conv2d_grouped(const void* table_dev, int32_t n, int32_t ki
     }
   }
   return check_launch("conv2d_grouped");
-}
-
-// ---- fused backward launch (see fused_bwd_kernel) ---------------------------------------------------------------------
-extern "C" int mxdet_fused_dgrad_wgrad(const void* conv_table_dev, int32_t cn, int32_t cfg, int32_t cgrid,
-                                       const void* wgrad_table_dev, int32_t wn, int32_t w_block_begin,
-                                       int32_t w_block_end, void* wgrad_workspace, mxdet_stream_t stream) {
-  clear_error();
-  MXDET_REQUIRE(conv_table_dev && cn > 0 && cgrid > 0 && wgrad_table_dev && wn > 0 && wgrad_workspace, MXDET_EINVAL,
-                "fused_dgrad_wgrad: null pointer or empty table");
-  MXDET_REQUIRE(cfg == 2 || cfg == 3, MXDET_EINVAL, "fused_dgrad_wgrad: only the 64x128 / 64x64 tile configurations fuse");
-  MXDET_REQUIRE(w_block_begin >= 0 && w_block_end > w_block_begin && w_block_begin % 8 == 0, MXDET_ESHAPE,
-                "fused_dgrad_wgrad: bad weight-gradient block range [%d, %d)", w_block_begin, w_block_end);
-  const int cpad = (cgrid + 7) & ~7;
-  const unsigned grid = (unsigned)(cpad + (w_block_end - w_block_begin));
-  hipStream_t s = as_stream(stream);
-  if (cfg == 2)
-    hipLaunchKernelGGL((fused_bwd_kernel<64, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, (const ConvG*)conv_table_dev, cn,
-                       cgrid, cpad, (const WgradG*)wgrad_table_dev, wn, w_block_begin, (unsigned char*)wgrad_workspace);
-  else
-    hipLaunchKernelGGL((fused_bwd_kernel<64, 64, 2, 2, 3>), dim3(grid), dim3(256), 0, s, (const ConvG*)conv_table_dev, cn,
-                       cgrid, cpad, (const WgradG*)wgrad_table_dev, wn, w_block_begin, (unsigned char*)wgrad_workspace);
-  return check_launch("fused_dgrad_wgrad");
 }

@@ -42,27 +42,19 @@ wgrad_kernel(WgradP p) {
 
 template <int BKP, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 2 ? 4 : (NS == 3 ? 3 : 2), 4)))
-wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace, int block_off,
-                     int total) {
-  // Persistent form: the grid may be smaller than the tile list (gridDim.x a multiple of 8 keeps logical tile -> XCD),
-  // each workgroup then walks tiles bid, bid + gridDim.x, ... A grid of one workgroup per CU places instantly and
-  // leaves the CU's other wave slots to the short dgrad kernels of the main stream, which a many-round grid would
-  // keep waiting until its last workgroup has been placed.
-  for (int bid = (int)blockIdx.x + block_off; bid < total; bid += (int)gridDim.x) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) >> 1;
-      if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
-    }
-    const int b = bid - table[lo].block0;
-    if (b < table[lo].nblocks) {                     // else: alignment padding between layers
-      WgradP p = table[lo].p;
-      p.slab = (float*)(workspace + (size_t)p.slab);
-      p.bslab = (float*)(workspace + (size_t)p.bslab);
-      wgrad_tile<BKP, NS>(p, b);
-    }
-    __syncthreads();                                 // LDS ring is reused by the next tile
+wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
+  const int bid = (int)blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
   }
+  const int b = bid - table[lo].block0;
+  if (b >= table[lo].nblocks) return;              // alignment padding between layers
+  WgradP p = table[lo].p;
+  p.slab = (float*)(workspace + (size_t)p.slab);
+  p.bslab = (float*)(workspace + (size_t)p.bslab);
+  wgrad_tile<BKP, NS>(p, b);
 }
 
 // the three-tap tiles (wgrad3_tile.h): 256 threads, NS * 25 KiB of LDS, two workgroups per CU
@@ -310,8 +302,6 @@ struct WgradPlan {
   size_t slab_bytes, bslab_off, bslab_bytes, total;
 };
 
-static int g_group_persist = 0;               // tuning hook (mxdet_debug_wgrad_group_persist), 0 = one workgroup per tile
-static int g_group_chunk = 0;                 // tuning hook (mxdet_debug_wgrad_group_chunk), 0 = one launch per group
 static thread_local int g_force_ksplit = 0;   // tuning hook (mxdet_debug_force_wgrad_ksplit), 0 = heuristic
 
 static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
@@ -360,16 +350,6 @@ static WgradPlan plan_wgrad(const mxdet_conv_desc_t* d) {
 }  // namespace mxdet
 
 using namespace mxdet;
-
-extern "C" int mxdet_debug_wgrad_group_persist(int32_t workgroups) {
-  g_group_persist = workgroups;
-  return MXDET_OK;
-}
-
-extern "C" int mxdet_debug_wgrad_group_chunk(int32_t workgroups) {
-  g_group_chunk = workgroups;
-  return MXDET_OK;
-}
 
 extern "C" int mxdet_debug_force_wgrad_ksplit(int32_t ks) {
   g_force_ksplit = ks;
@@ -647,9 +627,6 @@ extern "C" int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n
   MXDET_REQUIRE(workspace_needed == 0 || (workspace && workspace_bytes >= workspace_needed), MXDET_EWORKSPACE,
                 "wgrad_grouped: workspace %zu < %zu", workspace_bytes, workspace_needed);
   hipStream_t s = as_stream(stream);
-  // Optional chunking (tuning hook): a grid far larger than one resident round keeps the dispatcher on this queue until
-  // it has placed every workgroup, which starves the short dgrad kernels of the main stream; chunks of about one
-  // resident round let the two queues alternate at launch granularity.
   if (grid_big > 0 && grid_wgrad > 0 && tuning(MXDET_TUNE_T3_MIX) != 0 && (grid_big & 7) == 0 && (grid_wgrad & 7) == 0) {
     const int n3g = grid_big >> 3, n1g = grid_wgrad >> 3;
     if (tuning(MXDET_TUNE_T3_MIX) == 2)
@@ -669,60 +646,26 @@ extern "C" int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n
       hipLaunchKernelGGL((wgrad3_grouped_kernel<2>), dim3((unsigned)grid_big), dim3(256), 0, s, (const WgradG*)table_dev, n,
                          (unsigned char*)workspace);
   }
-  const int chunk = g_group_chunk > 0 ? g_group_chunk : (grid_wgrad > 0 ? grid_wgrad : 1);
-  const int persist = g_group_persist > 0 ? (g_group_persist + 7) & ~7 : 0;
-  for (int off = 0; off < grid_wgrad; off += chunk) {
-    const int cnt = grid_wgrad - off < chunk ? grid_wgrad - off : chunk;
-    const int grid = persist > 0 && persist < cnt ? persist : cnt;
+  if (grid_wgrad > 0) {
     // ring depth: 2 stages (32 KiB, 4 workgroups per CU), 3 (48 KiB, 3 per CU) or 4 (64 KiB, 2 per CU)
     switch ((int)tuning(MXDET_TUNE_WG_NS)) {
       case 3:
-        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 3>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
-                           (unsigned char*)workspace, off, off + cnt);
+        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 3>), dim3((unsigned)grid_wgrad), dim3(256), 0, s,
+                           (const WgradG*)table_dev, n, (unsigned char*)workspace);
         break;
       case 4:
-        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 4>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
-                           (unsigned char*)workspace, off, off + cnt);
+        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 4>), dim3((unsigned)grid_wgrad), dim3(256), 0, s,
+                           (const WgradG*)table_dev, n, (unsigned char*)workspace);
         break;
       default:
-        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid), dim3(256), 0, s, (const WgradG*)table_dev, n,
-                           (unsigned char*)workspace, off, off + cnt);
+        hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)grid_wgrad), dim3(256), 0, s,
+                           (const WgradG*)table_dev, n, (unsigned char*)workspace);
     }
   }
   if (grid_reduce > 0)
     hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)grid_reduce), dim3(256), 0, s,
                        (const WgradG*)table_dev, n, (const unsigned char*)workspace);
   return check_launch("conv2d_wgrad_grouped");
-}
-
-// first workgroup of every item of a planned group (host table), [n] = the grid: the fused backward launch issues a
-// group's tiles in slices that end on item boundaries whose inputs exist
-extern "C" int mxdet_conv2d_wgrad_grouped_item_blocks(const void* table_host, int32_t n, int32_t* block0_out) {
-  clear_error();
-  MXDET_REQUIRE(table_host && n > 0 && block0_out, MXDET_EINVAL, "wgrad_grouped_item_blocks: null pointer");
-  const WgradG* t = (const WgradG*)table_host;
-  for (int i = 0; i < n; ++i) block0_out[i] = t[i].block0;
-  block0_out[n] = (t[n - 1].block0 + t[n - 1].nblocks + 7) & ~7;
-  return MXDET_OK;
-}
-
-// the tiles [block_begin, grid_wgrad) of a group (the rest went out in fused backward launches), then the fold
-extern "C" int mxdet_conv2d_wgrad_grouped_from(const void* table_dev, int32_t n, int32_t block_begin, int32_t grid_wgrad,
-                                               int32_t grid_reduce, void* workspace, size_t workspace_bytes,
-                                               size_t workspace_needed, mxdet_stream_t stream) {
-  clear_error();
-  MXDET_REQUIRE(table_dev && n > 0 && grid_wgrad > 0 && block_begin >= 0 && block_begin <= grid_wgrad, MXDET_EINVAL,
-                "wgrad_grouped_from: bad range");
-  MXDET_REQUIRE(workspace_needed == 0 || (workspace && workspace_bytes >= workspace_needed), MXDET_EWORKSPACE,
-                "wgrad_grouped_from: workspace %zu < %zu", workspace_bytes, workspace_needed);
-  hipStream_t s = as_stream(stream);
-  if (block_begin < grid_wgrad)
-    hipLaunchKernelGGL((wgrad_grouped_kernel<kWgradBKP, 2>), dim3((unsigned)(grid_wgrad - block_begin)), dim3(256), 0, s,
-                       (const WgradG*)table_dev, n, (unsigned char*)workspace, block_begin, grid_wgrad);
-  if (grid_reduce > 0)
-    hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)grid_reduce), dim3(256), 0, s,
-                       (const WgradG*)table_dev, n, (const unsigned char*)workspace);
-  return check_launch("conv2d_wgrad_grouped_from");
 }
 
 extern "C" int mxdet_filter_transpose_batched(const void* descs_dev, int32_t ndesc, int32_t total_tiles,

@@ -92,7 +92,6 @@ class FasterRCNN(DetectorBase):
         """image NCHW [N,3,H,W]; gt_boxes [N,G,5] f32 (class < 0 padding); im_info [N,3] f32."""
         N, _, H, W = image.shape
         self.plan(N, H, W, gt_boxes.shape[1])
-        self._begin_step()
         early = self.early_anchor_targets and self.branch is not None
         if early:
             # anchor assignment needs the ground truth only: on the branch stream it runs underneath the backbone forward,

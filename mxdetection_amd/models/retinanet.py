@@ -59,7 +59,6 @@ class RetinaNet(DetectorBase):
     def forward_backward(self, image, gt_boxes, im_info, step=0, image_offset=0, step_dev=None, gt_masks=None):
         N, _, H, W = image.shape
         self.plan(N, H, W, gt_boxes.shape[1])
-        self._begin_step()
         C = self.backbone.forward(image)
         P = self.neck.forward(C[1:])
         self.head.forward(P)

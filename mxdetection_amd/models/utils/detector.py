@@ -254,21 +254,11 @@ class DetectorBase:
         interruptions of the dgrad chain (whole-step A/B: +1.3…2 % for two buckets instead of five at N = 1)."""
         return str(point) not in self.bucket_merge
 
-    def enable_fused_backward(self):
-        """Weight-gradient tiles ride in the data-gradient launches of the backward chain (needs grouped wgrad)."""
-        self.enable_grouped_wgrad()
-        self.ws.fusing = True
-
     def _guard_replan(self, key):
         """plan() at a new input shape reallocates buffers a captured step holds by address."""
         if self.segments is not None and self.planned is not None and self.planned != key:
             raise RuntimeError("the captured training step holds the buffers planned for %s; a call at %s would free "
                                "them (build a second model for another input shape)" % (self.planned, key))
-
-    def _begin_step(self):
-        self.ws.begin_step()
-        if getattr(self, "ws_rpn", None) is not None:
-            self.ws_rpn.begin_step()
 
     def enable_grouped_wgrad(self):
         """Issue the weight gradients of each bucket (box/mask heads, FPN, every ResNet stage) as one grouped launch."""

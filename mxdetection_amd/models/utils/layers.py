@@ -50,37 +50,6 @@ class Workspace:
         self.pending = []
         self.plans = {}
         self.gbuf = None
-        # fused backward (needs grouping): a bucket's weight-gradient tiles ride in the data-gradient launches of the
-        # chain as soon as their inputs exist; what is left at flush() goes out as before. The plan of the k-th flush
-        # of a step is the one the previous pass built at its k-th flush (the schedule is static).
-        self.fusing = False
-        self.quota = int(os.environ.get("MXDET_FUSE_QUOTA", "256"))
-        self.flush_plans = []       # per flush index: (key, plan, slab buffer of its own)
-        self.flush_idx = 0
-        self.issued = 0
-
-    def begin_step(self):
-        self.flush_idx = 0
-        self.issued = 0
-
-    def try_fuse(self, call):
-        """Data-gradient call + as many ready weight-gradient tiles of the current bucket as the quota allows."""
-        if not (self.fusing and self.grouping) or self.flush_idx >= len(self.flush_plans) \
-                or self.flush_plans[self.flush_idx] is None:
-            return False
-        key, plan, buf = self.flush_plans[self.flush_idx]
-        npend = len(self.pending)
-        if npend == 0 or npend > len(key):
-            return False
-        if tuple((id(l), x.data_ptr(), dy.data_ptr()) for l, x, dy in self.pending) != key[:npend]:
-            return False
-        take = min(plan.block0[npend] - self.issued, self.quota) // 8 * 8
-        if take <= 0:
-            return False
-        if not dense.fused_dgrad(call, self.device, plan, self.issued, self.issued + take, buf):
-            return False
-        self.issued += take
-        return True
 
     def defer(self, layer, x, dy):
         self.pending.append((layer, x, dy))
@@ -91,22 +60,12 @@ class Workspace:
             return
         items, self.pending = self.pending, []
         key = tuple((id(l), x.data_ptr(), dy.data_ptr()) for l, x, dy in items)
-        idx, issued = self.flush_idx, self.issued
-        self.flush_idx, self.issued = idx + 1, 0
-        if self.fusing and idx < len(self.flush_plans) and self.flush_plans[idx] is not None \
-                and self.flush_plans[idx][0] == key:
-            _, plan, buf = self.flush_plans[idx]
-            ctx = self.fork()
-            with (ctx if ctx is not None else contextlib.nullcontext()):
-                plan.launch_from(buf, issued)
-            return
-        assert issued == 0, "fused weight-gradient tiles were issued from a plan that does not match this bucket"
         plan = self.plans.get(key)
         capturing = torch.cuda.is_current_stream_capturing()
         if plan is None and not capturing:
             calls = [(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
                       l.arena.view(l.bi, "g") if l.train_bias else None, False) for l, x, dy in items]
-            plan = dense.GroupedWgrad(calls, self.device, fused=self.fusing)
+            plan = dense.GroupedWgrad(calls, self.device)
             self.plans[key] = plan
             if self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
                 self._retired.append(self.gbuf)
@@ -120,14 +79,6 @@ class Workspace:
                                        l.arena.view(l.bi, "g") if l.train_bias else None, False, self.get())
             else:
                 plan.launch(self.gbuf)
-        if self.fusing and plan is not None and not capturing:
-            # remember this bucket for the next pass; fused launches write its slabs from the main stream while the
-            # previous bucket's fold may still be reading: every bucket gets a slab buffer of its own
-            buf = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device=self.device)
-            while len(self.flush_plans) <= idx:
-                self.flush_plans.append(None)
-            self.flush_plans[idx] = (key, plan, buf)
-
     def fork(self):
         if self.side is None:
             return None
@@ -265,11 +216,6 @@ class ConvLayer:
 
     def backward_data(self, dy, x_shape, residual=None, relu_mask=None, accumulate=False, out=None, relu_bits=None):
         """relu_bits: the 1-bit form of relu_mask (read instead of it: 1/16 of the operand bytes)."""
-        if self.ws is not None and self.ws.fusing and self.stride == 1 and self.trainable:
-            if out is None:
-                out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
-            if self.ws.try_fuse(self.dgrad_call(dy, x_shape, residual, relu_mask, accumulate, out)):
-                return out
         if dense.PF_TRACE is not None:
             dense.PF_TRACE.append((self, "b", dense.mem_range(self.wt), None))
         return dense.conv2d_dgrad(dy, self.wt, x_shape, self.k, self.k, self.stride, self.pad, residual,

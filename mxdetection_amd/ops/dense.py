@@ -211,33 +211,12 @@ def conv2d_group(kind, calls, device):
                          relu_bits=c[11] if len(c) > 11 else None)
 
 
-def fused_dgrad(call, device, wplan, w_begin, w_end, wbuf):
-    """One data-gradient call (argument tuple of conv2d_dgrad, `out` given) + the weight-gradient tiles
-    [w_begin, w_end) of the planned group `wplan` as ONE launch (mxdet_fused_dgrad_wgrad). Returns False -- nothing
-    launched -- when this call cannot fuse (tile configuration, stride-2 path, table not built before a capture)."""
-    key = ("dgrad1",) + tuple(t.data_ptr() if torch.is_tensor(t) else t for t in call)
-    plan = _group_plans.get(key)
-    if plan is None:
-        if torch.cuda.is_current_stream_capturing() or call[5] != 1:
-            return False
-        try:
-            plan = GroupedConv("dgrad", [call], device)
-        except _lib.MxdetError:
-            plan = False
-        _group_plans[key] = plan
-    if plan is False or (plan.cfg & 3) not in (2, 3):    # (cfg = tile configuration + 4 x tap class)
-        return False
-    check(_lib.load().mxdet_fused_dgrad_wgrad(ptr(plan.table), plan.n, plan.cfg & 3, plan.grid, ptr(wplan.table), wplan.n,
-                                              w_begin, w_end, ptr(wbuf), stream_ptr()), "fused_dgrad_wgrad")
-    return True
-
-
 class GroupedWgrad:
     """Weight gradients of several layers as one launch pair (mxdet_conv2d_wgrad_grouped). `calls` is a list of
     (x, dy, KH, KW, stride, pad, dw, db, accumulate); the plan (device table, grids, workspace size) is built once, in
     eager mode, and stays valid while the tensors keep their addresses (e.g. under hipGraph replay)."""
 
-    def __init__(self, calls, device, fused=False):
+    def __init__(self, calls, device):
         lib = _lib.load()
         n = len(calls)
         items = (_lib.WgradItemT * n)()
@@ -255,49 +234,16 @@ class GroupedWgrad:
         nbytes = lib.mxdet_conv2d_wgrad_grouped_table_bytes(n)
         host = (C.c_ubyte * nbytes)()
         ws, gw, gb, gr = C.c_size_t(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        if fused:        # the fused backward launch slices the 256-thread kernel's tiles: no three-tap items
-            lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_ENABLE"], 0)
-        try:
-            check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gb),
-                                                      C.byref(gr)), "conv2d_wgrad_grouped_plan")
-        finally:
-            if fused:
-                lib.mxdet_debug_set_tuning(_lib.TUNING_KEYS["T3_ENABLE"], -1)
+        check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gb),
+                                                  C.byref(gr)), "conv2d_wgrad_grouped_plan")
         self.grid_big = gb.value
         self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
         self.n, self.grid_wgrad, self.grid_reduce, self.workspace_bytes = n, gw.value, gr.value, ws.value
-        b0 = (C.c_int32 * (n + 1))()
-        check(lib.mxdet_conv2d_wgrad_grouped_item_blocks(host, n, b0), "conv2d_wgrad_grouped_item_blocks")
-        self.block0 = list(b0)            # first workgroup of every item, [n] = end of the last one (8-aligned)
 
-    def launch_from(self, workspace, block_begin):
-        """The tiles from block_begin on (the earlier ones went out in fused backward launches), then the fold."""
-        check(_lib.load().mxdet_conv2d_wgrad_grouped_from(ptr(self.table), self.n, block_begin, self.grid_wgrad,
-                                                          self.grid_reduce, ptr(workspace), workspace.numel(),
-                                                          self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped_from")
-
-    def launch(self, workspace, side=None):
-        """side: a second stream for the one-tap kernel (1x1 / strided items, HBM-bound) so that it runs beside the
-        three-tap kernel (3x3 items, MFMA-bound) instead of behind it; the fold joins both."""
-        lib = _lib.load()
-        nb = workspace.numel() if workspace is not None else 0
-        if side is None or self.grid_big == 0 or self.grid_wgrad == 0:
-            check(lib.mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce,
-                                                 ptr(workspace), nb, self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
-            return
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            check(lib.mxdet_conv2d_wgrad_grouped_parts(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce, 2,
-                                                       ptr(workspace), nb, self.workspace_bytes, stream_ptr()),
-                  "conv2d_wgrad_grouped_parts")
-        check(lib.mxdet_conv2d_wgrad_grouped_parts(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce, 1,
-                                                   ptr(workspace), nb, self.workspace_bytes, stream_ptr()),
-              "conv2d_wgrad_grouped_parts")
-        cur.wait_stream(side)
-        check(lib.mxdet_conv2d_wgrad_grouped_parts(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce, 4,
-                                                   ptr(workspace), nb, self.workspace_bytes, stream_ptr()),
-              "conv2d_wgrad_grouped_parts")
+    def launch(self, workspace):
+        check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce,
+                                                     ptr(workspace), workspace.numel() if workspace is not None else 0,
+                                                     self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
 
 
 def filter_transpose(w, out=None):

@@ -61,11 +61,14 @@ def test_train_step_landscape_then_portrait_on_one_model(hip):
 
 
 def test_detector_learns_a_fixed_batch(hip):
-    """The detector can fit something: 400 replayed steps on ONE fixed 2-image batch (three objects painted into noise)
+    """The detector can fit something: 600 replayed steps on ONE fixed 2-image batch (three objects painted into noise)
     drive the box-head classification loss below 0.2 and every RPN / box loss far below its start, and predict() then
     returns exactly the ground truth: every GT box recovered at IoU >= 0.5 with its class, nothing else above score 0.3.
     The net has no normalisation layers and is positively homogeneous, so the input scale (0.2) sets the logit scale of
-    the random-init heads (start: box-head CE = ln 81); lr 0.01 with a 50-step warm-up."""
+    the random-init heads (start: box-head CE = ln 81); lr 0.005 with a 100-step warm-up. (At lr 0.01 / 50 warm-up steps the
+    run sat at the edge of stability: the step amplifies rounding-level differences ~100x, and half of the (model seed,
+    fp32 summation order) combinations spiked in the warm-up and collapsed to the all-background plateau or diverged --
+    tools/overfit_spread.py; at this setting 12 of 12 combinations fit the batch.)"""
     import torch
     from mxdetection_amd.models import FasterRCNN
     N, H, W = 2, 256, 320
@@ -86,11 +89,11 @@ def test_detector_learns_a_fixed_batch(hip):
     m.enable_wgrad_stream()
     m.enable_branch_stream()
     m.enable_grouped_wgrad()
-    lr = 0.01
+    lr = 0.005
     m.capture(image, gt, info, lr=lr)
     first = None
-    for it in range(400):
-        losses = m.replay(image, gt, info, it, lr=lr * min(1.0, (it + 1) / 50.0))
+    for it in range(600):
+        losses = m.replay(image, gt, info, it, lr=lr * min(1.0, (it + 1) / 100.0))
         if it == 0:
             torch.cuda.synchronize()
             first = torch.cat(list(losses)).cpu().numpy().copy()
@@ -253,33 +256,6 @@ def test_step_with_an_image_without_ground_truth(hip, kind):
     vals = torch.cat(list(losses)).cpu().numpy()
     assert np.all(np.isfinite(vals)), vals
     assert torch.isfinite(m.arena.g).all()
-
-
-def test_fused_backward_takes_the_same_step(hip):
-    """Experimental schedule (weight-gradient tiles riding in the data-gradient launches, mxdet_fused_dgrad_wgrad):
-    same kernels' arithmetic, so two steps leave bit-identical losses and parameters. (It is slower than the default
-    schedule; kept as a measured alternative.)"""
-    import torch
-    from mxdetection_amd.models import FasterRCNN
-    N, H, W = 2, 256, 320
-    image, gt, im_info = _inputs(N, H, W, seed=5)
-
-    def run(fused):
-        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
-        m.enable_wgrad_stream()
-        m.enable_grouped_wgrad()
-        if fused:
-            m.enable_fused_backward()
-        out = []
-        for step in range(3):        # step 0 builds the plans, steps 1-2 run fused
-            out.append(torch.cat(m.train_step(image, gt, im_info, step=step, lr=0.001)).clone())
-        torch.cuda.synchronize()
-        return torch.stack(out).cpu(), m.arena.w.clone(), m
-
-    l0, w0, _ = run(False)
-    l1, w1, m = run(True)
-    assert m.ws.flush_plans and any(p is not None for p in m.ws.flush_plans)
-    assert torch.equal(l0, l1) and torch.equal(w0, w1)
 
 
 def test_graph_replay_honours_momentum_and_wd(hip):
