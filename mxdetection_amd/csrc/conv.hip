@@ -977,6 +977,13 @@ static int launch(ConvP& p, hipStream_t s) {
       default: return MXDET_LAUNCH_ST(128, 128, 2, 2, 2);
     }
   }
+  // one partial round of 256 x 256 tiles that still covers most of the chip, with a long enough reduction to pay for the
+  // tile's prologue / epilogue (the box head's first FC, data gradient: 1,024 x 12,544 x 1,024 -> 196 tiles, 69 -> 33 us)
+  {
+    const long long t256 = (long long)(p.M / 256) * (p.Ncols / 256);
+    if (p.M % 256 == 0 && p.Ncols % 256 == 0 && t256 >= 160 && t256 <= 256 && K >= 1024 && p.m_begin == 0)
+      return launch_cfg<256, 256, 2, 4, 2, DGRAD>(p, s);
+  }
   // many rows, short reduction: 128 x 128 tiles of eight waves (64 x 32 per wave) -- half the LDS-DMA bytes per MFMA of
   // the 64 x 128 tile (the small tiles' K loop is bound by what a CU's vector-memory path takes in, ~64 B/clk)
   if (st != 0 && p.Ncols >= 128 && t128 >= tuning(MXDET_TUNE_T128W)) return MXDET_LAUNCH_ST(128, 128, 2, 4, 2);
@@ -1147,10 +1154,17 @@ extern "C" int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
   p.M = d->N * d->Ho * d->Wo;
   p.ksplit = ksplit; p.partial = (float*)workspace;
-  const long long tiles = (long long)ceil_div(p.M, 64) * ceil_div(p.Ncols, 64);
+  // tile: 64 x 64 (three workgroups per CU), or 128 x 128 (half the L2 -> LDS bytes per flop: the K loop of the small
+  // tile is bound by that path) when the layer still fills the chip with them (tuning key SPLITK_TILE: 0 / 1 / 2 = 128 x 128
+  // tiles of four / eight waves)
+  const int big = (int)tuning(MXDET_TUNE_SPLITK_TILE);
+  const int BT = big ? 128 : 64;
+  const long long tiles = (long long)ceil_div(p.M, BT) * ceil_div(p.Ncols, BT);
   MXDET_REQUIRE(tiles % 8 == 0, MXDET_ESHAPE, "conv2d_fwd_splitk: the tile count (%lld) must be a multiple of 8", tiles);
   hipStream_t s = as_stream(stream);
-  rc = launch_cfg<64, 64, 2, 2, 3, false, false, 1>(p, s);
+  if (big == 1) rc = launch_cfg<128, 128, 2, 2, 2, false, false, 1>(p, s);
+  else if (big == 2) rc = launch_cfg<128, 128, 2, 4, 2, false, false, 1>(p, s);
+  else rc = launch_cfg<64, 64, 2, 2, 3, false, false, 1>(p, s);
   if (rc) return rc;
   const long long total = (long long)p.M * p.Ncols;
   hipLaunchKernelGGL(conv_splitk_fold_kernel, dim3((unsigned)ceil_div<long long>(total / 8, 256)), dim3(256), 0, s,

@@ -34,6 +34,7 @@ class Bottleneck:
         self.down = ConvLayer(name + ".down", cin, planes * 4, 1, stride, 0, **kw) if downsample else None
         self.x = self.a1 = self.a2 = self.y = self.sc = None
         self.bufs = {}
+        self.y_key = "y"      # name of the output buffer (ResNet.forward_front switches the frozen front end's between two)
 
     def layers(self):
         return [l for l in (self.conv3, self.conv2, self.conv1, self.down) if l is not None]
@@ -97,12 +98,12 @@ class Bottleneck:
                 nb.a1 = nb._buf("a1", nb.conv1.out_shape(oshape))
                 kw = dict(w3=nb.conv1.w_bf16, bias3=nb.conv1.bias_f32, relu3=True, out3=nb.a1)
             r = dense.conv2d_forward_chain(self.a1, self.conv2.w_bf16, self.conv2.bias_f32, self.conv3.w_bf16,
-                                           self.conv3.bias_f32, sc, relu=True, relu2=True, out=self._buf("y", oshape),
+                                           self.conv3.bias_f32, sc, relu=True, relu2=True, out=self._buf(self.y_key, oshape),
                                            prefetch=self.conv2.pf_fwd, **kw)
             self.y = r[0] if nb is not None else r
             return self.y
         self.a2 = self.conv2.forward(self.a1, relu=True, out=self._buf("a2", s2), bits_out=self.a2_bits)
-        self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf("y", oshape), bits_out=self.y_bits)
+        self.y = self.conv3.forward(self.a2, relu=True, residual=sc, out=self._buf(self.y_key, oshape), bits_out=self.y_bits)
         return self.y
 
     def backward(self, ds, dx_buf, dx_has_grad):
@@ -160,6 +161,9 @@ class ResNet:
         self.stem_b = torch.zeros((64,), dtype=torch.float32, device=device)
         self.bufs = {}
         self.outs = None
+        self.front_override = None     # see forward()
+        self.eager_parity = 0          # which of the two front-end output buffers an eager forward() writes
+        self.front_outs = []
 
     def layers(self):
         return [l for st in self.stages for b in st for l in b.layers()]
@@ -175,7 +179,26 @@ class ResNet:
         return shapes
 
     def forward(self, image):
-        """image: NCHW [N,3,H,W] (f32 or bf16), read directly by the stem kernel."""
+        """image: NCHW [N,3,H,W] (f32 or bf16), read directly by the stem kernel. With front_override set (the captured
+        step of DetectorBase.capture: the frozen front end ran as a graph of its own) the image is not read: the trainable
+        stages start from that tensor."""
+        if self.front_override is not None:
+            return self.forward_rest(self.front_override)
+        return self.forward_rest(self.forward_front(image, self.eager_parity))
+
+    def frozen_front(self):
+        """Number of leading stages that are frozen (their output depends on the image only)."""
+        n = 0
+        for st in self.stages:
+            if any(b.trainable for b in st):
+                break
+            n += 1
+        return n
+
+    def forward_front(self, image, parity=0):
+        """Stem + max-pool + the frozen stages (C2 with the default frozen_stages = 1): a function of the image alone, so a
+        training step may compute it for the NEXT batch while the previous step still runs its weight-gradient tail. The
+        result lives in one of two buffers (parity): the previous step's backward still reads the other one."""
         N, _, H, W = image.shape
         H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         dev = self.stem_w.device
@@ -183,17 +206,37 @@ class ResNet:
         x = dense.stem_conv7x7_pool(image, self.stem_w, self.stem_b,
                                     cached_buf(self.bufs, "pool", (N, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1, 64),
                                                torch.bfloat16, dev))
-        outs = []
+        nf = self.frozen_front()
+        if nf > 0:
+            self.stages[nf - 1][-1].y_key = "y%d" % parity if parity else "y"
+        self.front_outs = []
+        for st in self.stages[:nf]:
+            x = self._stage_forward(st, x, None)
+            self.front_outs.append(x)
+        return x
+
+    def _stage_forward(self, st, x, xb):
+        ready = False
+        for i, b in enumerate(st):
+            nb = st[i + 1] if i + 1 < len(st) else None
+            ride = (CHAIN3_FROZEN and nb is not None and b.chainable() and nb.chainable() and nb.down is None and
+                    nb.conv1.cout == 64 and nb.conv1.stride == 1)
+            x = b.forward(x, xb, a1_ready=ready, next_block=nb if ride else None)
+            ready = ride
+            xb = b.y_bits
+        self._xb = xb
+        return x
+
+    def forward_rest(self, x):
+        nf = self.frozen_front()
+        if self.front_override is None:
+            outs = list(self.front_outs[:nf])
+        else:                               # only the last frozen stage's output exists as a tensor of this step
+            outs = ([None] * (nf - 1) + [x]) if nf else []
         xb = None                       # 1-bit ReLU mask of x, when its producer is a trainable block
-        for st in self.stages:
-            ready = False
-            for i, b in enumerate(st):
-                nb = st[i + 1] if i + 1 < len(st) else None
-                ride = (CHAIN3_FROZEN and nb is not None and b.chainable() and nb.chainable() and nb.down is None and
-                        nb.conv1.cout == 64 and nb.conv1.stride == 1)
-                x = b.forward(x, xb, a1_ready=ready, next_block=nb if ride else None)
-                ready = ride
-                xb = b.y_bits
+        for st in self.stages[nf:]:
+            x = self._stage_forward(st, x, xb)
+            xb = self._xb
             outs.append(x)
         self.outs = outs
         return outs

@@ -154,6 +154,8 @@ class FasterRCNN(DetectorBase):
             lo = self.mark_fpn
         for si in (3, 2, 1):
             self._backbone_stage_backward(si)
+            if si == 1:
+                self._mark_tail()        # the data-gradient chain ends here: the next step's frozen front end may start
             if si == 1 or self._bucket_here(5 - si):       # reduce points 2 (layer4), 3 (layer3); layer2 always closes
                 self._reduce(lo, self.stage_marks[si])
                 lo = self.stage_marks[si]

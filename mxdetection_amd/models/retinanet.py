@@ -83,6 +83,8 @@ class RetinaNet(DetectorBase):
                     b.backward(ds, self.dC[si - 1], True)
                 else:
                     b.backward(ds, None, False)
+            if si == 1:
+                self._mark_tail()
             if si == 1 or self._bucket_here(5 - si):
                 self._reduce(lo, self.stage_marks[si])
                 lo = self.stage_marks[si]

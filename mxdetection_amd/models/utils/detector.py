@@ -35,6 +35,12 @@ class DetectorBase:
         self._final_join_opt = False
         self._cap_opt = None      # (lr, momentum, wd) while capturing per-bucket update graphs (N > 1)
         self.opt_stream = None
+        # Captured step, frozen front end as a graph of its own (capture(): front_pipeline): the stem + frozen stages of
+        # batch k run on the front stream while step k-1 is still in its weight-gradient tail (they depend on the image
+        # only). _tail_event is recorded by a node of the main graph where that tail begins.
+        self.front_pipeline = os.environ.get("MXDET_TUNE_FRONT_PIPE", "1") != "0"
+        self._front = None        # {"graphs": [g0, g1], "segments": [s0, s1], "losses": [l0, l1], "stream", "ready", "count"}
+        self._tail_event = None
 
     def _finalize_params(self, layers, frozen_layers=()):
         self.layers = layers
@@ -432,23 +438,74 @@ class DetectorBase:
             self._cap_opt = (self.lr_dev,) + hyper
             for lo_hi in sorted(self._seen_buckets):
                 self._transpose_table(*lo_hi)
+        use_front = self.front_pipeline and self.backbone.frozen_front() > 0 and warmup > 0
+        if use_front:
+            from ...utils.hipgraph import GraphEvent
+            # the second output buffer of the front end and every plan keyed by it (grouped launches of the consumers)
+            # must exist before a capture: one more eager step on parity 1
+            snap = (self.arena.w.clone(), self.arena.m.clone())
+            self.backbone.eager_parity = 1
+            self.train_step(*self.static_in, step=0, image_offset=image_offset, lr=lr, gt_masks=self.static_masks,
+                            momentum=hyper[0], wd=hyper[1])
+            self.backbone.eager_parity = 0
+            torch.cuda.synchronize()
+            self.arena.w.copy_(snap[0])
+            self.arena.m.copy_(snap[1])
+            self.arena.refresh_bf16()
+            self.refresh_transposed()
+            del snap
+            torch.cuda.synchronize()
+            self._tail_event = GraphEvent()
+            fstream = self.branch if self.branch is not None else torch.cuda.Stream()
+            self._front = {"graphs": [], "segments": [], "losses": [], "stream": fstream, "count": 0,
+                           "ready": [torch.cuda.Event(), torch.cuda.Event()], "pool": torch.cuda.graph_pool_handle()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._cap = True
-            self._seg_begin()
-            self._upd, self._upd_done = (((self.lr_dev,) + hyper) if self.dist is None else None), []
-            losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
-                                           gt_masks=self.static_masks)
-            self._upd = None
-            self.optimizer_step(self.lr_dev, hyper[0], hyper[1])
-            self._seg_end()
-            if self._final_join_opt:
-                self.segments.append(("join_opt",))
-            self._cap = False
+        for parity in ((0, 1) if use_front else (0,)):
+            if use_front:
+                # the front end of this parity: its own graph, captured on the front stream
+                fs = self._front["stream"]
+                fs.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(fs):
+                    g.capture_begin(pool=self._front["pool"], capture_error_mode="thread_local")
+                    c2 = self.backbone.forward_front(self.static_in[0], parity)
+                    g.capture_end()
+                torch.cuda.current_stream().wait_stream(fs)
+                self._front["graphs"].append(g)
+                self.backbone.front_override = c2
+                self.segments = []
+                self._buckets = []
+                self._final_join_opt = False
+            with torch.cuda.stream(side):
+                self._cap = True
+                self._seg_begin()
+                self._upd, self._upd_done = (((self.lr_dev,) + hyper) if self.dist is None else None), []
+                losses = self.forward_backward(*self.static_in, step=0, image_offset=image_offset, step_dev=self.step_dev,
+                                               gt_masks=self.static_masks)
+                self._upd = None
+                self.optimizer_step(self.lr_dev, hyper[0], hyper[1])
+                self._seg_end()
+                if self._final_join_opt:
+                    self.segments.append(("join_opt",))
+                self._cap = False
+            if use_front:
+                self._front["segments"].append(self.segments)
+                self._front["losses"].append(losses)
+        self.backbone.front_override = None
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if use_front:
+            self._tail_event.record()            # the first replayed step has no predecessor to wait for
+            torch.cuda.synchronize()
         self.static_losses = losses
+
+    def _mark_tail(self):
+        """Called by forward_backward where the data-gradient chain has ended and only the last bucket's weight gradients,
+        fold and update remain: under capture with the front-end pipeline, an event-record node the NEXT step's front end
+        waits for (it then runs beside that tail: HBM-bound frozen convolutions next to MFMA-bound weight gradients)."""
+        if self._cap and self._front is not None and self._tail_event is not None:
+            self._tail_event.record_node()
 
     def replay(self, image, gt_boxes, im_info, step, gt_masks=None, lr=None):
         """One training step from the captured graphs; lr (if given) replaces the captured learning rate from here on."""
@@ -456,8 +513,25 @@ class DetectorBase:
         if lr is not None and lr != self._lr_host:
             self.lr_dev.fill_(float(lr))
             self._lr_host = lr
-        if image is not si[0]:
+        segments, losses = self.segments, self.static_losses
+        if self._front is not None:
+            # front end of THIS batch on the front stream, behind the previous step's tail mark (not behind its end)
+            fr = self._front
+            par = fr["count"] & 1
+            fr["count"] += 1
+            fs = fr["stream"]
+            if os.environ.get("MXDET_TUNE_FRONT_PIPE", "1") != "2":      # "2": no tail gate (as early as the stream allows)
+                self._tail_event.wait(fs)
+            with torch.cuda.stream(fs):
+                if image is not si[0]:
+                    si[0].copy_(image, non_blocking=True)
+                fr["graphs"][par].replay()
+                fr["ready"][par].record()
+            torch.cuda.current_stream().wait_event(fr["ready"][par])
+            segments, losses = fr["segments"][par], fr["losses"][par]
+        elif image is not si[0]:
             si[0].copy_(image, non_blocking=True)
+        if image is not si[0]:
             si[1].copy_(gt_boxes, non_blocking=True)
             si[2].copy_(im_info, non_blocking=True)
             if gt_masks is not None:
@@ -465,7 +539,7 @@ class DetectorBase:
         self.step_dev.fill_(step)
         fork_ev = None
         handles = {}
-        for seg in self.segments:
+        for seg in segments:
             if isinstance(seg, tuple):
                 if seg[0] == "wgrad":
                     ev = torch.cuda.Event()
@@ -504,7 +578,7 @@ class DetectorBase:
                     self.reducer.wait()
             else:
                 seg.replay()
-        return self.static_losses
+        return losses
 
     def optimizer_step(self, lr, momentum=0.9, wd=1e-4):
         self.ws.flush()
