@@ -26,6 +26,8 @@ def main():
     m.enable_branch_stream()
     m.enable_grouped_wgrad()
     m.enable_data_parallel(world)
+    if backend == "nccl":          # two devices: the exchange must go through the library's own collective (csrc/comm.hip)
+        assert m.comm is not None, "RCCL process group without the C-ABI communicator"
     dist.broadcast(m.arena.w, 0)
     m.arena.refresh_bf16()
     m.refresh_transposed()
