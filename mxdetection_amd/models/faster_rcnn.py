@@ -129,17 +129,22 @@ class FasterRCNN(DetectorBase):
         d_pooled = self.bbox_head.backward()
         if self.roi_bwd_gather:
             self._join_branch()                                       # dP[l] holds the RPN part
-            # (defer_rpn: the RPN head's weight gradients -- MFMA-bound, 285 us -- go to the side stream with this bucket,
-            # underneath the gather, instead of lengthening the branch)
-            # the head bucket's weight gradients, update and filter transposes go to the side stream FIRST: they are
-            # MFMA / HBM bound and run underneath the gather, which is latency-bound (dependent loads, ~200 us)
+            # (defer_rpn: the RPN head's weight gradients -- MFMA-bound -- go to the side stream with this bucket instead of
+            # lengthening the branch.) The gather is issued FIRST and the head bucket's weight gradients, update and filter
+            # transposes behind it (round 3: with the three-tap weight-gradient kernel the gather beside a 2,000-workgroup
+            # MFMA grid took 235-310 us instead of its 70-90 us alone; alone first, then the bucket beside the P2 data
+            # gradients, is +0.3 % on the step. MXDET_TUNE_ROI_FIRST=0: the round-2 order, bucket first)
             lo = 0
-            if self._bucket_here(0):
+            roi_first = os.environ.get("MXDET_TUNE_ROI_FIRST", "1") == "1"     # the gather first, alone; the bucket behind it
+            if self._bucket_here(0) and not roi_first:
                 self._reduce(0, self.mark_rpn, pre=self.ws_rpn if defer_rpn else None)
                 lo = self.mark_rpn
             self.roi_extractor.backward_gather(d_pooled.view(pooled.shape), self.dP[:4], accumulate=True)
             if self.with_mask:
                 self.mask_roi_extractor.backward_gather(d_mpooled, self.dP[:4], accumulate=True)
+            if self._bucket_here(0) and roi_first:
+                self._reduce(0, self.mark_rpn, pre=self.ws_rpn if defer_rpn else None)
+                lo = self.mark_rpn
         else:
             acc = self.roi_extractor.backward(d_pooled.view(pooled.shape), self.dP[:4], finalize=False)
             if self.with_mask:
