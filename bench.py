@@ -227,8 +227,10 @@ def instep_profile(model, timeout_s=240):
         stems = [i for i, x in enumerate(rows) if "stem_pool_kernel" in x[2] or "stem_conv_kernel" in x[2]]
         if len(stems) < 4:
             return None
-        steps = list(zip(stems[-4:-1], stems[-3:]))       # the last three complete steps
+        steps = list(zip(stems[-4:-1], stems[-3:]))       # the last three step periods (stem launch to stem launch)
         fam, wall = {}, 0.0
+        share = {}                                        # family -> wall time attributed to it (see below)
+        top = {}                                          # kernel symbol -> [device ms, launches]
         for lo, hi in steps:
             win = rows[lo:hi]
             wall += (rows[hi][0] - win[0][0]) * 1e-6
@@ -238,8 +240,33 @@ def instep_profile(model, timeout_s=240):
                     acc = fam.setdefault(k, [0.0, 0])
                     acc[0] += (e0 - s0) * 1e-6
                     acc[1] += 1
+                sym = name.split("(")[0].replace("void ", "")
+                t = top.setdefault(sym, [0.0, 0])
+                t[0] += (e0 - s0) * 1e-6
+                t[1] += 1
+            # Kernels of different streams overlap (weight gradients beside the data-gradient chain, the next step's
+            # frozen front end beside the weight-gradient tail): the sum of durations then exceeds the wall time they
+            # cost. `share`: every instant of the window is split evenly between the kernels running in it, so the shares
+            # of all kernels add up to the busy time of the step.
+            ev = sorted([(s0, 1, i) for i, (s0, e0, _) in enumerate(win)] + [(e0, 0, i) for i, (s0, e0, _) in enumerate(win)])
+            active, last = set(), None
+            for t, kind, i in ev:
+                if active and last is not None and t > last:
+                    dt = (t - last) * 1e-6 / len(active)
+                    for j in active:
+                        k = kernel_family(win[j][2])
+                        if k:
+                            share[k] = share.get(k, 0.0) + dt
+                last = t
+                if kind == 1:
+                    active.add(i)
+                else:
+                    active.discard(i)
         n = float(len(steps))
+        dom = max(top.items(), key=lambda kv: kv[1][0])
         return {"families_ms": {k: v[0] / n for k, v in fam.items()}, "kernels": {k: v[1] / n for k, v in fam.items()},
+                "families_share_ms": {k: v / n for k, v in share.items()},
+                "dominant_kernel": {"name": dom[0], "ms_per_step": dom[1][0] / n, "launches_per_step": dom[1][1] / n},
                 "step_ms": wall / n, "steps": len(steps)}
     except Exception:  # noqa: BLE001
         return None
@@ -507,6 +534,11 @@ def main():
                                "tflops": round(fl / t_use / 1e12, 1), "ms_per_step": round(1e3 * t_use, 3),
                                "share_of_step": round(t_use / (dt / args.steps), 3),
                                "warm_tflops": round(fl / tt / 1e12, 1), "warm_ms_per_step": round(1e3 * tt, 3)}
+                if instep and instep["families_share_ms"].get(k):
+                    # wall time of the step attributable to the family (overlapping kernels share each instant evenly)
+                    sh = instep["families_share_ms"][k] * 1e-3
+                    families[k]["attributed_ms_per_step"] = round(1e3 * sh, 3)
+                    families[k]["attributed_tflops"] = round(fl / sh / 1e12, 1)
             dom = max(families.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
             fl, tt, n = fam[dom]
             t_use = families[dom]["ms_per_step"] * 1e-3
@@ -518,6 +550,22 @@ def main():
                                        "warm: each conv launch of one step re-issued 8x inside a hipGraph replayed between HIP events",
                         "warm_frac": round(fl / tt / MFMA_PEAK_BF16, 4),
                         "flops_source": "2*M*N*K of every launch of the family logged in one eager step"}
+            if instep:
+                # durations are per kernel as the trace has them: kernels of different streams overlap (the next step's
+                # frozen front end runs beside the weight-gradient tail, weight gradients beside the data-gradient chain),
+                # so a family's sum of durations can exceed the wall time it costs; conv_families.*.attributed_* split every
+                # instant evenly between the kernels running in it
+                roofline["overlap_note"] = "sum of in-step kernel durations; overlapping streams inflate it (see attributed_* in conv_families)"
+                dk = instep.get("dominant_kernel")
+                if dk:
+                    roofline["dominant_kernel_symbol"] = {"name": dk["name"][:96], "ms_per_step": round(dk["ms_per_step"], 3),
+                                                          "launches_per_step": round(dk["launches_per_step"], 1)}
+                    if "wgrad_mixed_grouped_kernel" in dk["name"]:
+                        mixed = sum(e[1] for e in timer.log if e[0] == "conv_wgrad" and len(e[3]) > 0 and
+                                    getattr(e[3][0], "grid_big", 0) > 0 and getattr(e[3][0], "grid_wgrad", 0) > 0)
+                        if mixed > 0:
+                            roofline["dominant_kernel_symbol"]["tflops"] = round(mixed / (dk["ms_per_step"] * 1e-3) / 1e12, 1)
+                            roofline["dominant_kernel_symbol"]["frac"] = round(mixed / (dk["ms_per_step"] * 1e-3) / MFMA_PEAK_BF16, 4)
         # `traffic` = HBM-side bytes (L2 misses) of the WHOLE dominant family in one step, from the tracked summary of
         # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over an eager step (tools/pmc_step.sh; FETCH_SIZE
         # doubled for 16-B-per-lane reads as the microarch guide prescribes). It is measured evidence of this round's

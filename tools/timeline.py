@@ -14,15 +14,19 @@ if len(sgd) < 3:
     sys.exit("need >= 3 steps in the trace")
 lo, hi = sgd[-3], sgd[-2]
 win = rows[lo:hi]
-t0, t1 = win[0][0], max(r[1] for r in win)
-print("kernels in step: %d   wall %.3f ms" % (len(win), (t1 - t0) / 1e6))
+# the window runs from one launch of the stem kernel to the next: exactly one step period. (With the front-end pipeline
+# the stem of step k+1 starts inside step k's weight-gradient tail, so the window holds the tail of one step and the
+# body of the next; kernels that start inside it may end after it.)
+t0, t1 = win[0][0], rows[hi][0]
+print("kernels in step: %d   step period %.3f ms   (last kernel of the window ends at %.3f ms)" % (
+    len(win), (t1 - t0) / 1e6, (max(r[1] for r in win) - t0) / 1e6))
 per_q = collections.defaultdict(float)
 for s, e, n, q, st in win:
     per_q[(q, st)] += (e - s) / 1e6
 for k, v in sorted(per_q.items()):
     print("  queue/stream %s: busy %.3f ms" % (k, v))
 # union busy
-ev = sorted([(s, 1) for s, e, *_ in win] + [(e, -1) for s, e, *_ in win])
+ev = sorted([(s, 1) for s, e, *_ in win] + [(min(e, t1), -1) for s, e, *_ in win])
 busy = 0; depth = 0; last = None; gaps = []
 for t, d in ev:
     if depth > 0:
