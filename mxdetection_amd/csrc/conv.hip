@@ -873,10 +873,6 @@ conv_igemm_grouped_kernel(const ConvG* __restrict__ table, int n) {
   conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, false, TAPS>(p, b, nb);
 }
 
-}  // namespace mxdet
-#include "conv1x1_fs.h"
-namespace mxdet {
-
 static thread_local int g_force_cfg = 0;   // tuning hook (mxdet_debug_force_conv_cfg), 0 = heuristic
 
 // Tile-choice thresholds (mxdet_debug_set_tuning overrides them for sweeps: they only tune correctly on whole-step
@@ -938,8 +934,6 @@ static int launch(ConvP& p, hipStream_t s) {
   // (a forward 3x3 may be strided: its tap displacements do not depend on the stride; a strided data gradient may not)
   const int st = ((p.stride != 1 && (DGRAD || taps == 1)) || tuning(MXDET_TUNE_STATIC_TAPS) == 0) ? 0
                  : (taps == 1 && p.pad == 0) ? 1 : (p.KH == 3 && p.KW == 3 && p.pad == 1) ? 9 : 0;
-  // short-reduction 1x1 layers with many columns: the filter-stationary streaming kernel (conv1x1_fs.h)
-  if (st == 1 && force == 0 && fs1x1_ok(p)) return launch_fs1x1(p, s);
 #define MXDET_LAUNCH_ST(BM, BN, WM, WN, NS)                                                        \
   (st == 1 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 1>(p, s)                                 \
            : st == 9 ? launch_cfg<BM, BN, WM, WN, NS, DGRAD, false, 9>(p, s)                       \

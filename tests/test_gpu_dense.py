@@ -573,48 +573,3 @@ def test_relu_bitmask_forward_and_dgrad(hip):
         assert torch.equal(d_mask, d_bits)
         assert torch.all(d_bits[y <= 0] == 0)
 
-
-@pytest.mark.parametrize("N,H,W,K,Nc", [(2, 50, 84, 256, 1024), (2, 30, 44, 128, 512), (2, 25, 42, 512, 2048), (1, 33, 37, 256, 256),
-                                        (2, 40, 56, 128, 256)])
-def test_conv1x1_filter_stationary_bit_identical(hip, N, H, W, K, Nc):
-    """The filter-stationary streaming kernel of the short-reduction 1x1 layers (conv1x1_fs.h; route: K in {128, 256, 512},
-    >= 256 columns) against the general tile kernel on the same operands, bit for bit: forward with bias + residual + ReLU +
-    1-bit mask output (a bottleneck's expand layer), forward without residual (an FPN lateral), data gradient with
-    residual + 1-bit mask input (a reduce layer's gradient), data gradient accumulating into its output. Row counts that
-    are not multiples of the row tile, several row tiles per workgroup."""
-    import torch
-    from mxdetection_amd.ops import dense
-    tune = hip.load().mxdet_debug_set_tuning
-    g = torch.Generator(device="cuda").manual_seed(K + Nc)
-    x = torch.randn((N, H, W, K), device="cuda", generator=g).to(torch.bfloat16)
-    w = (torch.randn((Nc, 1, 1, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
-    bias = torch.randn((Nc,), device="cuda", generator=g)
-    res = torch.randn((N, H, W, Nc), device="cuda", generator=g).to(torch.bfloat16)
-    act = torch.randn((N, H, W, Nc), device="cuda", generator=g).clamp_min(0).to(torch.bfloat16)   # a post-ReLU activation
-    bits_act = torch.empty((N, H, W, Nc // 8), dtype=torch.uint8, device="cuda")
-    dense.conv2d_forward(x, w, None, None, 1, 0, False, False, out=torch.empty_like(res))            # (plans nothing)
-    outs = {}
-    for on in (0, 1):
-        tune(hip.TUNING_KEYS["FS1X1"], on)
-        try:
-            bits = torch.zeros((N, H, W, Nc // 8), dtype=torch.uint8, device="cuda")
-            y = dense.conv2d_forward(x, w, bias, res, 1, 0, True, False, bits_out=bits)
-            y2 = dense.conv2d_forward(x, w, bias, None, 1, 0, False, False)
-            # the mask operand of the data gradient, as a forward launch writes it: bits of (act > 0)
-            if on == 0:
-                ident = dense.conv2d_forward(x, w, None, act, 1, 0, True, False, bits_out=bits_act)   # any launch: only bits_act matters
-            # data gradient of a K -> Nc "reduce" layer seen from its input side: dy has K channels, dx has Nc
-            wt = w.view(Nc, K).contiguous().view(Nc, 1, 1, K)     # [Cin = Nc][1][1][Cout = K]: rows = dx channels
-            dx = dense.conv2d_dgrad(x, wt, (N, H, W, Nc), 1, 1, 1, 0, residual=res, relu_bits=bits_act)
-            dx2 = res.clone()
-            dense.conv2d_dgrad(x, wt, (N, H, W, Nc), 1, 1, 1, 0, accumulate=True, out=dx2)
-            torch.cuda.synchronize()
-            outs[on] = (y.clone(), bits.clone(), y2.clone(), dx.clone(), dx2.clone())
-        finally:
-            tune(hip.TUNING_KEYS["FS1X1"], -1)
-    for a, b, what in zip(outs[0], outs[1], ("fwd+res+relu", "relu bits", "fwd plain", "dgrad+res+mask", "dgrad accumulate")):
-        assert torch.equal(a, b), what
-    # and against torch fp32 on the same bf16 operands (the general kernel's own tolerance)
-    ref = torch.relu(x.float().view(-1, K) @ w.float().view(Nc, K).t() + bias + res.float().view(-1, Nc))
-    got = outs[1][0].float().view(-1, Nc)
-    assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
