@@ -147,6 +147,37 @@ def test_wgrad_side_stream_and_graph_replay_match_eager(hip):
     assert (g_ref - m.arena.g).abs().max().item() <= 1e-3 * denom
 
 
+def test_front_end_pipeline_follows_the_batches(hip):
+    """The captured step computes the frozen front end (stem + C2) of batch k as a graph of its own on another stream, into one
+    of two buffers, gated by an event node of step k-1 (DetectorBase.capture, front_pipeline). With lr = 0 (weights fixed)
+    every replayed step over a sequence of DIFFERENT batches must give the losses of an eager step on that batch: a stale or
+    torn C2 map (wrong parity, front end racing the previous step's backward) would show at once."""
+    import torch
+    from mxdetection_amd.models import FasterRCNN
+    N, H, W = 2, 256, 320
+    batches = [_inputs(N, H, W, seed=20 + k) for k in range(3)]
+    m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
+    m.enable_wgrad_stream()
+    m.enable_branch_stream()
+    m.enable_grouped_wgrad()
+    ref = [torch.cat(m.forward_backward(*batches[k], step=7, image_offset=0)).clone() for k in range(3)]
+    m.ws.join()
+    torch.cuda.synchronize()
+    m.capture(*batches[0], lr=0.0, image_offset=0, warmup=1)
+    assert m._front is not None and len(m._front["graphs"]) == 2          # the pipeline is on: two parities were captured
+    for it, k in enumerate((1, 2, 0, 0, 2, 1, 1)):
+        got = torch.cat(m.replay(*batches[k], 7)).clone()
+        torch.cuda.synchronize()
+        assert torch.allclose(ref[k], got, rtol=1e-4, atol=1e-5), (it, k, ref[k], got)
+    # back-to-back replays without a host synchronisation in between (the pipeline's normal mode)
+    outs = []
+    for k in (0, 1, 2, 1, 0, 2):
+        outs.append((k, torch.cat(m.replay(*batches[k], 7)).clone()))
+    torch.cuda.synchronize()
+    for k, got in outs:
+        assert torch.allclose(ref[k], got, rtol=1e-4, atol=1e-5), (k, ref[k], got)
+
+
 def test_gradient_exchange_path_matches_single_gpu_step(hip):
     """The N > 1 schedule (graph cut at every bucket's all-reduce, per-bucket update graphs on the optimizer stream)
     run at world size 1 over RCCL must take the same step as the single-GPU schedule: same losses, parameters equal up
