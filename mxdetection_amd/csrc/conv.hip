@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   const int pf_bid = bid, pf_nwg = nwg;            // as launched: the prefetch hint's slices are dealt by this index
   int ks = 0, sl_begin = 0, sl_end = p.C >> 6;     // split-K (static 1x1 path): this workgroup's range of channel slices
   int nwg_ = nwg;
-  if constexpr (TAPS > 0) {
+  if constexpr (TAPS == 1) {
     if (p.ksplit > 1) {
       const int tiles = p.tiles_m * p.tiles_n;       // a multiple of 8 keeps every tile on its XCD (the host checks)
       ks = bid / tiles;
@@ -751,7 +751,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
       const int row = ps * RPP + rl;
       float4 v0 = *(const float4*)(ep + row * EP_STRIDE + cg * 8);
       float4 v1 = *(const float4*)(ep + row * EP_STRIDE + cg * 8 + 4);
-      if constexpr (TAPS > 0) {
+      if constexpr (TAPS == 1) {
         if (p.ksplit > 1) {                          // split-K: raw sums; bias / residual / ReLU happen in the fold kernel
           if (oks[ps]) {
             float* dst = p.partial + ((size_t)ks * p.M + pixs[ps]) * e_ncols + col;
@@ -895,7 +895,7 @@ static int launch_cfg(ConvP& p, hipStream_t s) {
   if (p.tiles_m <= 0) p.tiles_m = ceil_div(p.M - p.m_begin, BM);   // caller may restrict the row range
   p.tiles_n = ceil_div(p.Ncols, BN);
   long long nwg = (long long)p.tiles_m * p.tiles_n;
-  if (TAPS > 0 && p.ksplit > 1) nwg *= p.ksplit;
+  if (TAPS == 1 && p.ksplit > 1) nwg *= p.ksplit;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, NS, DGRAD, PAR, TAPS, CHAIN>), dim3((unsigned)nwg),
                      dim3(64 * WM * WN), 0, s, p);
   return check_launch("conv2d");
@@ -1138,9 +1138,8 @@ extern "C" int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_
   clear_error();
   int rc = validate(d, "conv2d_fwd_splitk");
   if (rc) return rc;
-  const bool is3 = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1;
-  MXDET_REQUIRE(((d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0) || is3) && !d->res_upsample, MXDET_ESHAPE,
-                "conv2d_fwd_splitk: 1x1 / stride 1 / pad 0 (fully connected) or 3x3 / stride 1 / pad 1 layers only");
+  MXDET_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->res_upsample, MXDET_ESHAPE,
+                "conv2d_fwd_splitk: 1x1 / stride 1 / pad 0 layers (fully connected) only");
   MXDET_REQUIRE(d->Cin % 64 == 0 && d->Cout % 8 == 0, MXDET_ESHAPE, "conv2d_fwd_splitk: Cin %% 64, Cout %% 8");
   MXDET_REQUIRE(ksplit >= 1 && ksplit <= d->Cin / 64, MXDET_ESHAPE, "conv2d_fwd_splitk: 1 <= ksplit <= Cin / 64");
   MXDET_REQUIRE(x && w && y, MXDET_EINVAL, "conv2d_fwd_splitk: null pointer");
@@ -1152,7 +1151,7 @@ extern "C" int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_
   p.x = x; p.w = w; p.bias = nullptr; p.res = nullptr; p.mask = nullptr; p.y = y;
   p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.C = d->Cin;
   p.Hd = d->Ho; p.Wd = d->Wo; p.Ncols = d->Cout;
-  p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->pad;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
   p.M = d->N * d->Ho * d->Wo;
   p.ksplit = ksplit; p.partial = (float*)workspace;
   // tile: 64 x 64 (three workgroups per CU), or 128 x 128 (half the L2 -> LDS bytes per flop: the K loop of the small
@@ -1161,14 +1160,9 @@ extern "C" int mxdet_conv2d_fwd_splitk(const mxdet_conv_desc_t* d, const uint16_
   const int big = (int)tuning(MXDET_TUNE_SPLITK_TILE);
   const int BT = big ? 128 : 64;
   const long long tiles = (long long)ceil_div(p.M, BT) * ceil_div(p.Ncols, BT);
-  // (a tile count that is a multiple of 8 keeps the splits of a tile on one XCD; others only lose that L2 locality)
-  (void)tiles;
+  MXDET_REQUIRE(tiles % 8 == 0, MXDET_ESHAPE, "conv2d_fwd_splitk: the tile count (%lld) must be a multiple of 8", tiles);
   hipStream_t s = as_stream(stream);
-  if (is3) {     // (split over the 64-channel slices; every split walks all nine taps of its slices)
-    if (big == 1) rc = launch_cfg<128, 128, 2, 2, 2, false, false, 9>(p, s);
-    else if (big == 2) rc = launch_cfg<128, 128, 2, 4, 2, false, false, 9>(p, s);
-    else rc = launch_cfg<64, 64, 2, 2, 3, false, false, 9>(p, s);
-  } else if (big == 1) rc = launch_cfg<128, 128, 2, 2, 2, false, false, 1>(p, s);
+  if (big == 1) rc = launch_cfg<128, 128, 2, 2, 2, false, false, 1>(p, s);
   else if (big == 2) rc = launch_cfg<128, 128, 2, 4, 2, false, false, 1>(p, s);
   else rc = launch_cfg<64, 64, 2, 2, 3, false, false, 1>(p, s);
   if (rc) return rc;

@@ -478,26 +478,6 @@ def test_conv_fwd_splitk_vs_torch(hip):
         assert (y - ref).abs().max().item() <= 2.0 ** -7 * scale            # one bf16 rounding of the result
         assert (y - base).abs().max().item() <= 2.0 ** -7 * scale
     assert torch.equal(dense.conv2d_forward_splitk(x, w, b, res, True, 1).float().view(R, Cout), base)
-    # 3x3 / stride 1 / pad 1 (every split walks the nine taps of its channel slices), on all three split-K tile choices
-    import ctypes as C
-    lib = hip.load()
-    N, H, W, Ch = 2, 19, 23, 256
-    x3 = torch.randn((N, H, W, Ch), device="cuda", generator=g).to(torch.bfloat16)
-    w3 = (torch.randn((Ch, 3, 3, Ch), device="cuda", generator=g) * 0.03).to(torch.bfloat16)
-    base3 = dense.conv2d_forward(x3, w3, b, None, 1, 1, True).float()
-    d = dense.conv_desc(N, H, W, Ch, Ch, 3, 3, 1, 1, True)
-    y3 = torch.empty((N, H, W, Ch), dtype=torch.bfloat16, device="cuda")
-    ws = torch.empty((4 * y3.numel() * 4,), dtype=torch.uint8, device="cuda")
-    for tile in (0, 1, 2):
-        lib.mxdet_debug_set_tuning(hip.TUNING_KEYS["SPLITK_TILE"], tile)
-        try:
-            for ks in (2, 4):
-                hip.check(lib.mxdet_conv2d_fwd_splitk(C.byref(d), hip.ptr(x3), hip.ptr(w3), hip.ptr(b), None, hip.ptr(y3), ks,
-                                                      hip.ptr(ws), ws.numel(), hip.stream_ptr()), "conv2d_fwd_splitk 3x3")
-                torch.cuda.synchronize()
-                assert (y3.float() - base3).abs().max().item() <= 2.0 ** -7 * base3.abs().max().item(), (tile, ks)
-        finally:
-            lib.mxdet_debug_set_tuning(hip.TUNING_KEYS["SPLITK_TILE"], -1)
 
 
 def test_conv_eight_wave_tile_route_bit_identical(hip):
