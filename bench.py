@@ -222,8 +222,25 @@ def instep_profile(model, timeout_s=240):
         rows = []
         with open(files[0]) as f:
             for x in csv.DictReader(f):
-                rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"]))
+                rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"], x.get("Queue_Id", "0")))
         rows.sort()
+        # The frozen front end (stem + frozen stages) is a graph of its own that runs on another stream beside the PREVIOUS
+        # step's weight-gradient tail (DetectorBase.capture, front_pipeline): its convolution kernels are a family of
+        # their own -- the forward launches that follow the stem kernel on the stem's queue, up to that queue's next
+        # kernel of another kind. (Their durations are long BECAUSE they share the chip with the tail; the step is shorter.)
+        front_left = {}
+        tagged = []
+        for s0, e0, name, q in rows:
+            fam_name = kernel_family(name)
+            if "stem_pool_kernel" in name or "stem_conv_kernel" in name:
+                front_left[q] = True
+            elif front_left.get(q):
+                if fam_name == "conv_igemm_fwd":
+                    fam_name = "conv_frozen_front"
+                else:
+                    front_left[q] = False
+            tagged.append((s0, e0, name, fam_name))
+        rows = tagged
         stems = [i for i, x in enumerate(rows) if "stem_pool_kernel" in x[2] or "stem_conv_kernel" in x[2]]
         if len(stems) < 4:
             return None
@@ -234,8 +251,7 @@ def instep_profile(model, timeout_s=240):
         for lo, hi in steps:
             win = rows[lo:hi]
             wall += (rows[hi][0] - win[0][0]) * 1e-6
-            for s0, e0, name in win:
-                k = kernel_family(name)
+            for s0, e0, name, k in win:
                 if k:
                     acc = fam.setdefault(k, [0.0, 0])
                     acc[0] += (e0 - s0) * 1e-6
@@ -248,13 +264,13 @@ def instep_profile(model, timeout_s=240):
             # frozen front end beside the weight-gradient tail): the sum of durations then exceeds the wall time they
             # cost. `share`: every instant of the window is split evenly between the kernels running in it, so the shares
             # of all kernels add up to the busy time of the step.
-            ev = sorted([(s0, 1, i) for i, (s0, e0, _) in enumerate(win)] + [(e0, 0, i) for i, (s0, e0, _) in enumerate(win)])
+            ev = sorted([(w_[0], 1, i) for i, w_ in enumerate(win)] + [(w_[1], 0, i) for i, w_ in enumerate(win)])
             active, last = set(), None
             for t, kind, i in ev:
                 if active and last is not None and t > last:
                     dt = (t - last) * 1e-6 / len(active)
                     for j in active:
-                        k = kernel_family(win[j][2])
+                        k = win[j][3]
                         if k:
                             share[k] = share.get(k, 0.0) + dt
                 last = t
@@ -509,8 +525,20 @@ def main():
         saved = model.reducer
         model.reducer = BucketReducer(model.arena.g, None)
         timer.logging = True
-        model.forward_backward(*batches[0], step=10 ** 6, image_offset=rank * BATCH_PER_GPU,
-                               gt_masks=masks[0] if masks else None)   # eager, logged
+        # launches issued by the frozen front end (stem + frozen stages) are logged as a family of their own
+        ff = model.backbone.forward_front
+
+        def front_logged(*a, **kw):
+            n0 = len(timer.log)
+            out = ff(*a, **kw)
+            timer.log[n0:] = [("conv_frozen_front",) + e[1:] if e[0] == "conv_igemm_fwd" else e for e in timer.log[n0:]]
+            return out
+        model.backbone.forward_front = front_logged
+        try:
+            model.forward_backward(*batches[0], step=10 ** 6, image_offset=rank * BATCH_PER_GPU,
+                                   gt_masks=masks[0] if masks else None)   # eager, logged
+        finally:
+            model.backbone.forward_front = ff
         timer.logging = False
         torch.cuda.synchronize()
         fam = timer.measure()
