@@ -437,6 +437,8 @@ def main():
         model.broadcast_parameters(0)
     # linear-scaling rule from lr 0.02 @ batch 16, at the warm-up start factor 1/3 (random-init weights, no BN)
     lr = 0.02 * (BATCH_PER_GPU * world) / 16.0 / 3.0
+    if os.environ.get("MXDET_ABL_LR0") == "1":      # timing-only ablation builds (tools/ab_env.sh): wrong gradients must not feed back
+        lr = 0.0
     batches = [synth_batch(rank, s, device) for s in range(4)]
     masks = None
     if args.model == "mask_rcnn":   # filled ellipse inside every GT box, [N,16,H,W] u8 (GT rows 0..15 are the valid ones)

@@ -30,7 +30,9 @@ namespace mxdet {
 template <int BKP, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 wgrad_kernel(WgradP p) {
-  wgrad_tile<BKP, NS>(p, (int)blockIdx.x);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * 2 * BKP * 256];
+  if (wgrad_plain(p)) wgrad_tile<BKP, NS, true>(p, (int)blockIdx.x, smem);
+  else wgrad_tile<BKP, NS, false>(p, (int)blockIdx.x, smem);
 }
 
 // ---- grouped form: the weight gradients of MANY layers in one launch ----------------------------------------------
@@ -43,6 +45,7 @@ wgrad_kernel(WgradP p) {
 template <int BKP, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 2 ? 4 : (NS == 3 ? 3 : 2), 4)))
 wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __restrict__ workspace) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * 2 * BKP * 256];
   const int bid = (int)blockIdx.x;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -54,7 +57,8 @@ wgrad_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned char* __r
   WgradP p = table[lo].p;
   p.slab = (float*)(workspace + (size_t)p.slab);
   p.bslab = (float*)(workspace + (size_t)p.bslab);
-  wgrad_tile<BKP, NS>(p, b);
+  if (wgrad_plain(p)) wgrad_tile<BKP, NS, true>(p, b, smem);
+  else wgrad_tile<BKP, NS, false>(p, b, smem);
 }
 
 // the three-tap tiles (wgrad3_tile.h): 256 threads, NS * 25 KiB of LDS, two workgroups per CU
@@ -118,7 +122,8 @@ wgrad_mixed_grouped_kernel(const WgradG* __restrict__ table, int n, unsigned cha
     WgradP p = table[lo].p;
     p.slab = (float*)(workspace + (size_t)p.slab);
     p.bslab = (float*)(workspace + (size_t)p.bslab);
-    wgrad_tile<kWgradBKP, NS1, true>(p, b, smem);
+    if (wgrad_plain(p)) wgrad_tile<kWgradBKP, NS1, true>(p, b, smem);
+    else wgrad_tile<kWgradBKP, NS1, false>(p, b, smem);
   }
 }
 
@@ -537,8 +542,8 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
     // measured sweep (profiles/r01_h_grouped_wgrad_sweep.txt): ~3072 workgroups per group, 64..128 steps each
     // (mxdet_debug_set_tuning overrides for whole-step sweeps, e.g. shorter workgroups for the fused backward launch)
     const long long target = tuning(MXDET_TUNE_WG_TARGET);
-    const int min_steps = (int)tuning(MXDET_TUNE_WG_MINSTEPS);
-    const int max_steps = (int)tuning(MXDET_TUNE_WG_MAXSTEPS);
+    const int min_steps = (int)tuning(MXDET_TUNE_WG_MINSTEPS) * 32 / kWgradBKP;      // the tunings count 32-pixel steps
+    const int max_steps = (int)tuning(MXDET_TUNE_WG_MAXSTEPS) * 32 / kWgradBKP;
     long long want = tiles_total > 0 ? (target + tiles_total - 1) / tiles_total : 1;
     int ks = (int)want;
     const int max_ks = steps / min_steps > 0 ? steps / min_steps : 1, min_ks = ceil_div(steps, max_steps);

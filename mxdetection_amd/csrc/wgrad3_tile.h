@@ -171,7 +171,11 @@ __device__ __forceinline__ void wgrad3_tile(const WgradP& p, int b, unsigned cha
     unsigned char* sx = sy + kT3DyBytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#ifdef MXDET_WG_L2TEST   /* diagnostic: every workgroup streams the same 1 MiB (wrong results, timing only) */
+      const unsigned vy = y_wv[i] < W ? (y_off[i] & 0xfffffu) : kDmaOob;
+#else
       const unsigned vy = y_wv[i] < W ? y_off[i] : kDmaOob;
+#endif
 #ifndef MXDET_ABL_NOLOAD
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lptr_t)(sy + (wid * 4 + i) * 1024), 16, (int)vy, 0, 0, 0);
 #else
@@ -186,7 +190,11 @@ __device__ __forceinline__ void wgrad3_tile(const WgradP& p, int b, unsigned cha
     for (int k = 0; k < 3; ++k) {
       if (k == 2 && wid != 3) break;                // wave-uniform
       const bool ok = (x_wv[k] < W) && ((unsigned)x_hi[k] < (unsigned)H);
+#ifdef MXDET_WG_L2TEST
+      const unsigned vx = ok ? (x_off[k] & 0xfffffu) : kDmaOob;
+#else
       const unsigned vx = ok ? x_off[k] : kDmaOob;
+#endif
       const int pj = k < 2 ? wid * 2 + k : 8;
 #ifndef MXDET_ABL_NOLOAD
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(sx + pj * 1024), 16, (int)vx, 0, 0, 0);

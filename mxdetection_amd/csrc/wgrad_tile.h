@@ -1,6 +1,5 @@
-// wgrad_tile.h -- the weight-gradient tile (device function) and its parameter blocks, shared by wgrad.hip (plain and
-// grouped launches) and conv.hip (the fused backward launch: a layer's data-gradient tiles and weight-gradient tiles
-// in one grid). See wgrad.hip for the algorithm notes.
+// wgrad_tile.h -- the one-tap weight-gradient tile (device function) and the parameter blocks of both tile kinds, used by
+// wgrad.hip (plain, grouped and mixed launches). See wgrad.hip for the algorithm notes.
 #pragma once
 #include "common.h"
 
@@ -11,7 +10,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int kWgradBKP = 32;   // pixels per step (32: 32 KiB of LDS -> 4+ workgroups per CU)
+#ifndef MXDET_WGRAD_BKP
+#define MXDET_WGRAD_BKP 32
+#endif
+constexpr int kWgradBKP = MXDET_WGRAD_BKP;   // pixels per ring stage (32: 16 KiB per stage; 64: two MFMA k-steps per barrier)
 struct WgradP {
   const uint16_t* x;   // [N,H,W,Cin]
   const uint16_t* dy;  // [N,Ho,Wo,Cout]
@@ -31,6 +33,11 @@ struct WgradP {
   int t3_nwg, t3_ci_tiles, t3_ksplit, t3_steps;
 };
 
+// 1x1 / stride 1 / pad 0 (and FC) layers take the PLAIN form of the tile's load bookkeeping (wave-uniform)
+__device__ __forceinline__ bool wgrad_plain(const WgradP& p) {
+  return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+}
+
 // byte offset inside a [64 px][256 B] image of 16-B chunk c16 of pixel row `row`
 __device__ __forceinline__ int wg_off(int row, int c16) {
   int f = (row & 3) | (((row >> 3) & 1) << 2);
@@ -45,22 +52,74 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* lds_base, int by
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// One 32-pixel MFMA k-step of a stage (HH = which 32 rows of the stage's images): 16 transposed fragment reads, 16 MFMAs.
+// Fragment reads in inline asm: behind the ds_read_tr builtin hipcc cannot tell that the read does not touch the ring
+// slot an LDS-DMA is still filling and drains vmcnt(0) before the first read of every step (measured: the ring then
+// overlaps nothing). The asm reads are ordered by hand: LDS returns in issue order, the first fence (lgkmcnt(4)) releases
+// the x fragments and the first two dy fragments, the second the rest, so the last four reads are still in flight under
+// the first eight MFMAs. The fences name the registers they release.
+template <int BKP, int HH>
+__device__ __forceinline__ void wgrad_half(unsigned sbase, const unsigned (&offy)[4], const unsigned (&offx)[4],
+                                           f32x4_t (&acc)[4][4]) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t bx[4], ay[4];
+    // (each fragment is packed right where its two reads are issued: with the reads hoisted into arrays first the
+    // compiler copied every half into place -- 64 v_mov per step on a loop that is vector-issue bound)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ad = sbase + (unsigned)(BKP * 256) + offx[j];
+      s16x4_t lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad), "n"(HH * 8192));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ad), "n"(HH * 8192 + 1024));
+      bx[j] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ad = sbase + offy[i];
+      s16x4_t lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad), "n"(HH * 8192));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ad), "n"(HH * 8192 + 1024));
+      ay[i] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(4)"
+                 : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]), "+v"(ay[0]), "+v"(ay[1]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#ifndef MXDET_ABL_NOMFMA
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ay[i]),
+                                                            __builtin_bit_cast(bf16x8_t, bx[j]), acc[i][j], 0, 0, 0);
+#else
+        asm volatile("" ::"v"(ay[i]), "v"(bx[j]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);   // keep the first eight MFMAs above the second fence
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ay[2]), "+v"(ay[3]));
+#pragma unroll
+    for (int i = 2; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#ifndef MXDET_ABL_NOMFMA
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ay[i]),
+                                                            __builtin_bit_cast(bf16x8_t, bx[j]), acc[i][j], 0, 0, 0);
+#else
+        asm volatile("" ::"v"(ay[i]), "v"(bx[j]));
+#endif
+}
+
 // One workgroup = one 128(co) x 128(ci) tile of one tap over a range of 64-pixel steps. Global -> LDS is a
 // 2-stage LDS-DMA ring (global_load_lds_dwordx4, 1 KiB per wave instruction = 4 pixel rows x 256 B): the loads
 // of step t+1 are in flight while step t is multiplied; one s_waitcnt vmcnt(0) + one raw s_barrier per step.
 // The LDS image is lane-linear, so the granule swizzle is applied to the per-lane SOURCE chunk.
-template <int BKP, int NS, bool EXT_LDS = false>
-__device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char* lds_pool = nullptr) {
+// PLAIN: the layer is a 1x1 / stride 1 / pad 0 convolution (or an FC layer): source pixel = output pixel, so a lane's two
+// offsets advance by constants and the descriptor's range check alone ends the tensor -- 8 vector instructions of
+// bookkeeping per step instead of ~50 (the K loop is issue-bound, see below).
+template <int BKP, int NS, bool PLAIN>
+__device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char* lds_pool) {
   constexpr int GI = BKP / 16;      // DMA instructions per wave per image per stage (4 pixel rows each)
   static_assert(NS >= 2 && (NS - 2) * 2 * (BKP / 16) <= 63, "vmcnt is a 6-bit counter");
   typedef unsigned char lds_img_t[2][BKP * 256];                                  // [dy|x] image of one stage
-  lds_img_t* smem;                                                                // [buf][dy|x]
-  if constexpr (EXT_LDS) {
-    smem = (lds_img_t*)lds_pool;
-  } else {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem_own[NS][2][BKP * 256];
-    smem = smem_own;
-  }
+  lds_img_t* const smem = (lds_img_t*)lds_pool;                                    // [buf][dy|x], NS * 2 * BKP * 256 bytes, the kernel's
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -161,7 +220,33 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
     c_xok[i] = (ci0 + chunk) < p.Cin;
   }
   const int stepy = BKP * p.Cout;
+  // PLAIN: byte offsets, pre-multiplied; a lane whose channels lie outside the tensor carries the out-of-range pattern in
+  // `kill` for good (OR-ed in: offsets are 16-byte aligned), dummy stages past the end OR it in through a scalar
+  unsigned pl_offy[GI], pl_offx[GI], pl_killy[GI], pl_killx[GI];
+  if constexpr (PLAIN) {
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+      pl_offy[i] = 2u * (unsigned)c_offy[i];
+      pl_offx[i] = 2u * (unsigned)c_offx[i];
+      pl_killy[i] = c_yok[i] ? 0u : kDmaOob;
+      pl_killx[i] = c_xok[i] ? 0u : kDmaOob;
+    }
+  }
+  const unsigned pl_stepy = 2u * (unsigned)BKP * (unsigned)p.Cout, pl_stepx = 2u * (unsigned)BKP * (unsigned)p.Cin;
   auto issue_stage = [&](int buf, bool live) {
+    if constexpr (PLAIN) {
+      const unsigned dead = live ? 0u : kDmaOob;      // scalar
+#pragma unroll
+      for (int i = 0; i < GI; ++i) {
+        const unsigned vy = pl_offy[i] | pl_killy[i] | dead;
+        const unsigned vx = pl_offx[i] | pl_killx[i] | dead;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lptr_t)(smem[buf][0] + (wid * GI + i) * 1024), 16, (int)vy, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(smem[buf][1] + (wid * GI + i) * 1024), 16, (int)vx, 0, 0, 0);
+        pl_offy[i] += pl_stepy;
+        pl_offx[i] += pl_stepx;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < GI; ++i) {
       const bool mok = live && c_m[i] < p.M;
@@ -204,7 +289,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
   // 16-channel block; it receives channel (lane&15) of those four pixel rows.
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 
-  static_assert(BKP == 32, "one 32-pixel MFMA k-step per ring stage");
+  static_assert(BKP == 32 || BKP == 64, "one or two 32-pixel MFMA k-steps per ring stage");
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&smem[0][0][0];
   unsigned offy[4], offx[4];
   {
@@ -228,56 +313,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradP& p, int b, unsigned char
     __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done with the buffer refilled next
     asm volatile("" ::: "memory");
     issue_stage(nxt, st + NS - 1 < nsteps);
-    // Fragment reads in inline asm: behind the ds_read_tr builtin hipcc cannot tell that the read does not touch
-    // the ring slot an LDS-DMA is still filling and drains vmcnt(0) before the first read of every step (measured:
-    // the ring then overlaps nothing). The asm reads are ordered by hand: LDS returns in issue order, the first
-    // fence (lgkmcnt(4)) releases the x fragments and the first two dy fragments, the second the rest, so the last
-    // four reads are still in flight under the first eight MFMAs. The fences name the registers they release.
     const unsigned sbase = smem_addr + (unsigned)cur * (2u * BKP * 256u);
-    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-    s16x8_t bx[4], ay[4];
-    // (each fragment is packed right where its two reads are issued: with the reads hoisted into arrays first the
-    // compiler copied every half into place -- 64 v_mov per step on a loop that is vector-issue bound)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned ad = sbase + (unsigned)(BKP * 256) + offx[j];
-      s16x4_t lo, hi;
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
-      bx[j] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned ad = sbase + offy[i];
-      s16x4_t lo, hi;
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
-      ay[i] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-    asm volatile("s_waitcnt lgkmcnt(4)"
-                 : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]), "+v"(ay[0]), "+v"(ay[1]));
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#ifndef MXDET_ABL_NOMFMA
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ay[i]),
-                                                            __builtin_bit_cast(bf16x8_t, bx[j]), acc[i][j], 0, 0, 0);
-#else
-        asm volatile("" ::"v"(ay[i]), "v"(bx[j]));
-#endif
-    __builtin_amdgcn_sched_barrier(0);   // keep the first eight MFMAs above the second fence
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ay[2]), "+v"(ay[3]));
-#pragma unroll
-    for (int i = 2; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#ifndef MXDET_ABL_NOMFMA
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ay[i]),
-                                                            __builtin_bit_cast(bf16x8_t, bx[j]), acc[i][j], 0, 0, 0);
-#else
-        asm volatile("" ::"v"(ay[i]), "v"(bx[j]));
-#endif
+    wgrad_half<BKP, 0>(sbase, offy, offx, acc);
+    if constexpr (BKP == 64) wgrad_half<BKP, 1>(sbase, offy, offx, acc);
     cur = (cur + 1 == NS) ? 0 : cur + 1;
     nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }

@@ -157,10 +157,15 @@ class FasterRCNN(DetectorBase):
         if self._bucket_here(1):
             self._reduce(lo, self.mark_fpn)
             lo = self.mark_fpn
+        # where the next step's frozen front end may start: behind the backward of backbone stage `tail_at` (1 = where the
+        # data-gradient chain ends; 2 / 3 = one / two stages earlier, 4 = before the backbone's backward)
+        tail_at = int(os.environ.get("MXDET_TUNE_TAIL_AT", "1"))
+        if tail_at >= 4:
+            self._mark_tail()
         for si in (3, 2, 1):
             self._backbone_stage_backward(si)
-            if si == 1:
-                self._mark_tail()        # the data-gradient chain ends here: the next step's frozen front end may start
+            if si == tail_at:
+                self._mark_tail()
             if si == 1 or self._bucket_here(5 - si):       # reduce points 2 (layer4), 3 (layer3); layer2 always closes
                 self._reduce(lo, self.stage_marks[si])
                 lo = self.stage_marks[si]

@@ -10,6 +10,11 @@ from .dp import BucketReducer, make_comm
 from .layers import ParamArena, Workspace
 
 
+# TIMING-ONLY ablations (tools/ablate_step.sh): MXDET_ABL_SKIP=front,sgd,transpose,wgrad leaves the named component out of the
+# replayed step -- results are wrong, only the step time means anything (the marginal cost of a component in the overlapped
+# schedule, which the sum of its kernel durations overstates). Never set outside that tool.
+_ABL = frozenset(t for t in os.environ.get("MXDET_ABL_SKIP", "").split(",") if t)
+
 class DetectorBase:
     def _init_base(self, device):
         self.device = device
@@ -364,9 +369,10 @@ class DetectorBase:
         from ...ops import dense
         lr, momentum, wd = hyper
         a = self.arena
-        dense.sgd_momentum_update(a.w[lo:hi], a.g[lo:hi], a.m[lo:hi], a.wb[lo:hi], lr, momentum, wd, rescale)
+        if "sgd" not in _ABL:
+            dense.sgd_momentum_update(a.w[lo:hi], a.g[lo:hi], a.m[lo:hi], a.wb[lo:hi], lr, momentum, wd, rescale)
         table = self._transpose_table(lo, hi)
-        if table is not None:
+        if table is not None and "transpose" not in _ABL:
             dense.filter_transpose_batched(*table)
 
     # ---- hipGraph capture of the whole step (static shapes): removes ~450 host launches per step ----
@@ -567,7 +573,8 @@ class DetectorBase:
             with torch.cuda.stream(fs):
                 if image is not si[0]:
                     si[0].copy_(image, non_blocking=True)
-                fr["graphs"][par].replay()
+                if "front" not in _ABL:
+                    fr["graphs"][par].replay()
                 fr["ready"][par].record()
             torch.cuda.current_stream().wait_event(fr["ready"][par])
             segments, losses = fr["segments"][par], fr["losses"][par]
