@@ -196,6 +196,72 @@ def kernel_family(name):
     return None
 
 
+def instep_from_rows(rows):
+    """Per-family device time of the last three complete steps of a kernel trace. rows: (start_ns, end_ns, kernel name,
+    queue id) of every dispatch. Returns None if the trace holds fewer than four stem launches."""
+    rows = sorted(rows)
+    # The frozen front end (stem + frozen stages) is a graph of its own that runs on another stream beside the PREVIOUS
+    # step's weight-gradient tail (DetectorBase.capture, front_pipeline): its convolution kernels are a family of
+    # their own -- the forward launches that follow the stem kernel on the stem's queue, up to that queue's next
+    # kernel of another kind. (Their durations are long BECAUSE they share the chip with the tail; the step is shorter.)
+    front_left = {}
+    tagged = []
+    for s0, e0, name, q in rows:
+        fam_name = kernel_family(name)
+        if "stem_pool_kernel" in name or "stem_conv_kernel" in name:
+            front_left[q] = True
+        elif front_left.get(q):
+            if fam_name == "conv_igemm_fwd":
+                fam_name = "conv_frozen_front"
+            else:
+                front_left[q] = False
+        tagged.append((s0, e0, name, fam_name))
+    rows = tagged
+    stems = [i for i, x in enumerate(rows) if "stem_pool_kernel" in x[2] or "stem_conv_kernel" in x[2]]
+    if len(stems) < 4:
+        return None
+    steps = list(zip(stems[-4:-1], stems[-3:]))       # the last three step periods (stem launch to stem launch)
+    fam, wall = {}, 0.0
+    share = {}                                        # family -> wall time attributed to it (see below)
+    top = {}                                          # kernel symbol -> [device ms, launches]
+    for lo, hi in steps:
+        win = rows[lo:hi]
+        wall += (rows[hi][0] - win[0][0]) * 1e-6
+        for s0, e0, name, k in win:
+            if k:
+                acc = fam.setdefault(k, [0.0, 0])
+                acc[0] += (e0 - s0) * 1e-6
+                acc[1] += 1
+            sym = name.split("(")[0].replace("void ", "")
+            t = top.setdefault(sym, [0.0, 0])
+            t[0] += (e0 - s0) * 1e-6
+            t[1] += 1
+        # Kernels of different streams overlap (weight gradients beside the data-gradient chain, the next step's
+        # frozen front end beside the weight-gradient tail): the sum of durations then exceeds the wall time they
+        # cost. `share`: every instant of the window is split evenly between the kernels running in it, so the shares
+        # of all kernels add up to the busy time of the step.
+        ev = sorted([(w_[0], 1, i) for i, w_ in enumerate(win)] + [(w_[1], 0, i) for i, w_ in enumerate(win)])
+        active, last = set(), None
+        for t, kind, i in ev:
+            if active and last is not None and t > last:
+                dt = (t - last) * 1e-6 / len(active)
+                for j in active:
+                    k = win[j][3]
+                    if k:
+                        share[k] = share.get(k, 0.0) + dt
+            last = t
+            if kind == 1:
+                active.add(i)
+            else:
+                active.discard(i)
+    n = float(len(steps))
+    dom = max(top.items(), key=lambda kv: kv[1][0])
+    return {"families_ms": {k: v[0] / n for k, v in fam.items()}, "kernels": {k: v[1] / n for k, v in fam.items()},
+            "families_share_ms": {k: v / n for k, v in share.items()},
+            "dominant_kernel": {"name": dom[0], "ms_per_step": dom[1][0] / n, "launches_per_step": dom[1][1] / n},
+            "step_ms": wall / n, "steps": len(steps)}
+
+
 def instep_profile(model, timeout_s=240):
     """Kernel durations INSIDE replayed steps: a child process runs a short replay of the same model under
     `rocprofv3 --kernel-trace` (started before this process touches the GPU, like the ranks of --gpus N); the trace's
@@ -223,67 +289,7 @@ def instep_profile(model, timeout_s=240):
         with open(files[0]) as f:
             for x in csv.DictReader(f):
                 rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"], x.get("Queue_Id", "0")))
-        rows.sort()
-        # The frozen front end (stem + frozen stages) is a graph of its own that runs on another stream beside the PREVIOUS
-        # step's weight-gradient tail (DetectorBase.capture, front_pipeline): its convolution kernels are a family of
-        # their own -- the forward launches that follow the stem kernel on the stem's queue, up to that queue's next
-        # kernel of another kind. (Their durations are long BECAUSE they share the chip with the tail; the step is shorter.)
-        front_left = {}
-        tagged = []
-        for s0, e0, name, q in rows:
-            fam_name = kernel_family(name)
-            if "stem_pool_kernel" in name or "stem_conv_kernel" in name:
-                front_left[q] = True
-            elif front_left.get(q):
-                if fam_name == "conv_igemm_fwd":
-                    fam_name = "conv_frozen_front"
-                else:
-                    front_left[q] = False
-            tagged.append((s0, e0, name, fam_name))
-        rows = tagged
-        stems = [i for i, x in enumerate(rows) if "stem_pool_kernel" in x[2] or "stem_conv_kernel" in x[2]]
-        if len(stems) < 4:
-            return None
-        steps = list(zip(stems[-4:-1], stems[-3:]))       # the last three step periods (stem launch to stem launch)
-        fam, wall = {}, 0.0
-        share = {}                                        # family -> wall time attributed to it (see below)
-        top = {}                                          # kernel symbol -> [device ms, launches]
-        for lo, hi in steps:
-            win = rows[lo:hi]
-            wall += (rows[hi][0] - win[0][0]) * 1e-6
-            for s0, e0, name, k in win:
-                if k:
-                    acc = fam.setdefault(k, [0.0, 0])
-                    acc[0] += (e0 - s0) * 1e-6
-                    acc[1] += 1
-                sym = name.split("(")[0].replace("void ", "")
-                t = top.setdefault(sym, [0.0, 0])
-                t[0] += (e0 - s0) * 1e-6
-                t[1] += 1
-            # Kernels of different streams overlap (weight gradients beside the data-gradient chain, the next step's
-            # frozen front end beside the weight-gradient tail): the sum of durations then exceeds the wall time they
-            # cost. `share`: every instant of the window is split evenly between the kernels running in it, so the shares
-            # of all kernels add up to the busy time of the step.
-            ev = sorted([(w_[0], 1, i) for i, w_ in enumerate(win)] + [(w_[1], 0, i) for i, w_ in enumerate(win)])
-            active, last = set(), None
-            for t, kind, i in ev:
-                if active and last is not None and t > last:
-                    dt = (t - last) * 1e-6 / len(active)
-                    for j in active:
-                        k = win[j][3]
-                        if k:
-                            share[k] = share.get(k, 0.0) + dt
-                last = t
-                if kind == 1:
-                    active.add(i)
-                else:
-                    active.discard(i)
-        n = float(len(steps))
-        dom = max(top.items(), key=lambda kv: kv[1][0])
-        return {"families_ms": {k: v[0] / n for k, v in fam.items()}, "kernels": {k: v[1] / n for k, v in fam.items()},
-                "families_share_ms": {k: v / n for k, v in share.items()},
-                "dominant_kernel": {"name": dom[0], "ms_per_step": dom[1][0] / n, "launches_per_step": dom[1][1] / n},
-                "step_ms": wall / n, "steps": len(steps)}
+        return instep_from_rows(rows)
     except Exception:  # noqa: BLE001
         return None
     finally:
