@@ -419,30 +419,6 @@ int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wg
 int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
                                      int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
                                      size_t workspace_needed, mxdet_stream_t stream);
-/* Grouped weight gradients whose fold applies the optimizer step itself (single-GPU training: no exchange sits between
- * the gradient and its update). MXNet role: the per-parameter `sgd_mom_update` that follows backward. Every dw / db of the
- * group must lie inside ONE fp32 gradient arena; the parameter, momentum and bf16-copy arenas are addressed by the same
- * element offsets. _plan_update checks that and routes EVERY item through split-K slabs + fold (also single-split ones);
- * _update launches tiles + fold, the fold computing for each element  g = sum of slabs (+ old dw if accumulate);
- * g' = g * rescale + wd * w;  m = momentum * m + g';  w -= lr * m  -- bit for bit mxdet_sgd_momentum_update's arithmetic --
- * and refreshing w_bf16. The folded gradient is written to dw / db only if write_grad != 0 (it costs a write the update
- * does not need). lr_dev != NULL: the learning rate is read from device memory when the kernel runs (hipGraph replay). */
-typedef struct {
-  const float* grad;   /* base of the fp32 gradient arena (items' dw / db point into it) */
-  float* w;            /* fp32 parameters, same offsets */
-  float* mom;          /* fp32 momentum, same offsets */
-  uint16_t* w_bf16;    /* bf16 working copy, same offsets; may be NULL */
-  const float* lr_dev; /* NULL: use lr */
-  float lr, momentum, wd, rescale;
-  int32_t write_grad;
-} mxdet_sgd_arena_t;
-int mxdet_conv2d_wgrad_grouped_plan_update(const mxdet_wgrad_item_t* items, int32_t n, const float* grad_arena,
-                                           int64_t arena_elems, void* table_host, size_t table_bytes,
-                                           size_t* workspace_bytes, int32_t* grid_wgrad, int32_t* grid_big,
-                                           int32_t* grid_reduce);
-int mxdet_conv2d_wgrad_grouped_update(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
-                                      int32_t grid_reduce, void* workspace, size_t workspace_bytes,
-                                      size_t workspace_needed, const mxdet_sgd_arena_t* arena, mxdet_stream_t stream);
 /* w [Cout,KH,KW,Cin] -> wt [Cin,KH,KW,Cout] (bf16) */
 int mxdet_filter_transpose(const uint16_t* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                            uint16_t* wt, mxdet_stream_t stream);

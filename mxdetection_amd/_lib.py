@@ -58,14 +58,6 @@ class ConvDescT(C.Structure):
 
 
 WgradItemT._fields_ = [("desc", ConvDescT), ("x", c_vp), ("dy", c_vp), ("dw", c_vp), ("db", c_vp)]
-
-
-class SgdArenaT(C.Structure):          # mxdet_sgd_arena_t
-    _fields_ = [("grad", c_vp), ("w", c_vp), ("mom", c_vp), ("w_bf16", c_vp), ("lr_dev", c_vp),
-                ("lr", C.c_float), ("momentum", C.c_float), ("wd", C.c_float), ("rescale", C.c_float),
-                ("write_grad", c_i32)]
-
-
 ConvItemT._fields_ = [("desc", ConvDescT), ("src", c_vp), ("filt", c_vp), ("bias", c_vp), ("residual", c_vp),
                       ("relu_mask", c_vp), ("dst", c_vp)]
 
@@ -146,9 +138,6 @@ SIGNATURES = {
     "mxdet_conv2d_wgrad_grouped_plan": (c_i32, [P(WgradItemT), c_i32, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32), P(c_i32)]),
     "mxdet_conv2d_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
     "mxdet_conv2d_wgrad_grouped_parts": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, c_vp]),
-    "mxdet_conv2d_wgrad_grouped_plan_update": (c_i32, [P(WgradItemT), c_i32, c_vp, c_i64, c_vp, c_sz, P(c_sz), P(c_i32), P(c_i32),
-                                                       P(c_i32)]),
-    "mxdet_conv2d_wgrad_grouped_update": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_sz, P(SgdArenaT), c_vp]),
     "mxdet_debug_force_conv_cfg": (c_i32, [c_i32]),
     "mxdet_debug_force_wgrad_ksplit": (c_i32, [c_i32]),
     "mxdet_filter_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

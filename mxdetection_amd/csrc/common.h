@@ -76,15 +76,6 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return mxdet_f32_to_bf16(f); }
-
-// One SGD-with-momentum step of one parameter, with the rounding order pinned (three fused multiply-adds and one multiply),
-// so that the optimizer kernel (dense_misc.hip) and the weight-gradient fold that applies the update itself (wgrad.hip)
-// produce the same bits:  g' = g * rescale + wd * w;  m' = momentum * m + g';  w' = w - lr * m'
-__device__ __forceinline__ void sgd_apply(float& w, float& m, float g, float lr, float mom, float wd, float rescale) {
-  const float gr = __fmaf_rn(g, rescale, __fmul_rn(wd, w));
-  m = __fmaf_rn(mom, m, gr);
-  w = __fmaf_rn(-lr, m, w);
-}
 // two floats -> packed bf16 pair by the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even: the same bits as
 // mxdet_f32_to_bf16 for every finite value; NaNs keep being NaNs). One instruction instead of ~12 integer ones: used
 // by the dense epilogues, whose results are tolerance-checked; the bit-exact detection ops keep the shared helper.

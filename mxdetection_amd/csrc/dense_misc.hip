@@ -551,7 +551,11 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
     float4 wv = *(float4*)(w + i), gv = *(const float4*)(g + i), mv = *(float4*)(m + i);
     float ww[4] = {wv.x, wv.y, wv.z, wv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sgd_apply(ww[k], mm[k], gg[k], lr, mom, wd, rescale);
+    for (int k = 0; k < 4; ++k) {
+      float gr = gg[k] * rescale + wd * ww[k];
+      mm[k] = mom * mm[k] + gr;
+      ww[k] = ww[k] - lr * mm[k];
+    }
     *(float4*)(w + i) = make_float4(ww[0], ww[1], ww[2], ww[3]);
     *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     if (wb) {
@@ -562,11 +566,11 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
     }
   } else {
     for (long long j = i; j < n; ++j) {
-      float wv = w[j], mv = m[j];
-      sgd_apply(wv, mv, g[j], lr, mom, wd, rescale);
+      float gr = g[j] * rescale + wd * w[j];
+      float mv = mom * m[j] + gr;
       m[j] = mv;
-      w[j] = wv;
-      if (wb) wb[j] = f32_to_bf16_bits(wv);
+      w[j] = w[j] - lr * mv;
+      if (wb) wb[j] = f32_to_bf16_bits(w[j]);
     }
   }
 }

@@ -168,16 +168,8 @@ wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bs
 }
 
 // fold kernel of the grouped form: one launch for every layer of the group
-// UPD: the fold applies the SGD-momentum update itself (mxdet_conv2d_wgrad_grouped_update): the folded gradient never
-// goes to memory (unless u.write_grad), the parameter / momentum / bf16-copy arenas are addressed by the gradient's offset
-// in the gradient arena. Same arithmetic as sgd_kernel (sgd_apply).
-struct WgradUpd {
-  const float* grad; float* w; float* mom; uint16_t* wb; const float* lr_dev;
-  float lr, momentum, wd, rescale; int write_grad;
-};
-template <bool UPD>
 __global__ void __launch_bounds__(256)
-wgrad_reduce_grouped_kernel(const WgradG* __restrict__ table, int n, const unsigned char* __restrict__ workspace, WgradUpd u) {
+wgrad_reduce_grouped_kernel(const WgradG* __restrict__ table, int n, const unsigned char* __restrict__ workspace) {
   int lo = 0, hi = n - 1;
   const int bid = (int)blockIdx.x;
   while (lo < hi) {
@@ -198,17 +190,7 @@ wgrad_reduce_grouped_kernel(const WgradG* __restrict__ table, int n, const unsig
     if (c >= Cout) return;
     float s = bslab[c];
     for (int k = 1; k < ksplit; ++k) s += bslab[(size_t)k * Cout + c];
-    if (accumulate) s += db[c];
-    if (!UPD || u.write_grad) db[c] = s;
-    if constexpr (UPD) {
-      const long long off = (db + c) - u.grad;
-      const float lr = u.lr_dev ? *u.lr_dev : u.lr;
-      float wv = u.w[off], mv = u.mom[off];
-      sgd_apply(wv, mv, s, lr, u.momentum, u.wd, u.rescale);
-      u.w[off] = wv;
-      u.mom[off] = mv;
-      if (u.wb) u.wb[off] = f32_to_bf16_bits(wv);
-    }
+    db[c] = accumulate ? db[c] + s : s;
     return;
   }
   long long i = ((long long)b * blockDim.x + threadIdx.x) * 4;
@@ -234,23 +216,7 @@ wgrad_reduce_grouped_kernel(const WgradG* __restrict__ table, int n, const unsig
     float4 o = *(const float4*)(dw + i);
     s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
   }
-  if (!UPD || u.write_grad) *(float4*)(dw + i) = s;
-  if constexpr (UPD) {
-    const long long off = (dw + i) - u.grad;
-    const float lr = u.lr_dev ? *u.lr_dev : u.lr;
-    float4 wv = *(const float4*)(u.w + off), mv = *(const float4*)(u.mom + off);
-    float ww[4] = {wv.x, wv.y, wv.z, wv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, gg[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) sgd_apply(ww[k2], mm[k2], gg[k2], lr, u.momentum, u.wd, u.rescale);
-    *(float4*)(u.w + off) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-    *(float4*)(u.mom + off) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    if (u.wb) {
-      uint2 o;
-      o.x = (unsigned)f32_to_bf16_bits(ww[0]) | ((unsigned)f32_to_bf16_bits(ww[1]) << 16);
-      o.y = (unsigned)f32_to_bf16_bits(ww[2]) | ((unsigned)f32_to_bf16_bits(ww[3]) << 16);
-      *(uint2*)(u.wb + off) = o;
-    }
-  }
+  *(float4*)(dw + i) = s;
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]
@@ -482,11 +448,9 @@ extern "C" size_t mxdet_conv2d_wgrad_grouped_table_bytes(int32_t n) {
   return n > 0 ? (size_t)n * sizeof(WgradG) : 0;
 }
 
-// force_all: every item's gradient goes through slabs and the fold, also where one split would let the tile write dw / db
-// itself (the fold that applies the update, mxdet_conv2d_wgrad_grouped_update, must see every gradient)
-static int plan_wgrad_grouped(const mxdet_wgrad_item_t* items, int32_t n, bool force_all, void* table_host,
-                              size_t table_bytes, size_t* workspace_bytes, int32_t* grid_wgrad, int32_t* grid_big,
-                              int32_t* grid_reduce) {
+extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, void* table_host,
+                                               size_t table_bytes, size_t* workspace_bytes, int32_t* grid_wgrad,
+                                               int32_t* grid_big, int32_t* grid_reduce) {
   clear_error();
   MXDET_REQUIRE(items && n > 0 && table_host && workspace_bytes && grid_wgrad && grid_big && grid_reduce, MXDET_EINVAL,
                 "wgrad_grouped_plan: null pointer or empty group");
@@ -618,12 +582,12 @@ static int plan_wgrad_grouped(const mxdet_wgrad_item_t* items, int32_t n, bool f
                     "wgrad_grouped_plan: items %d and %d share dw but differ in shape or db", i, j);
       t[j].p.slab = (float*)(slab0 + (size_t)ks0 * params * sizeof(float));
       t[j].p.bslab = (float*)(bslab0 + (size_t)ks0 * cout * sizeof(float));
-      t[j].p.force_slab = (members > 1 || force_all) ? 1 : 0;
+      t[j].p.force_slab = members > 1 ? 1 : 0;
       ks0 += t[j].p.ksplit;
     }
     WgradG& g = t[i];
     g.fold_ksplit = total_ks;
-    const bool fold = members > 1 || g.p.ksplit > 1 || force_all;
+    const bool fold = members > 1 || g.p.ksplit > 1;
     g.wblocks = fold ? (int)ceil_div<long long>((long long)params / 4, 256) : 0;
     g.bblocks = (fold && g.p.db) ? ceil_div((int)cout, 256) : 0;
     // the owner's fold reads from the start of the run
@@ -641,57 +605,11 @@ static int plan_wgrad_grouped(const mxdet_wgrad_item_t* items, int32_t n, bool f
   return MXDET_OK;
 }
 
-extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, int32_t n, void* table_host,
-                                               size_t table_bytes, size_t* workspace_bytes, int32_t* grid_wgrad,
-                                               int32_t* grid_big, int32_t* grid_reduce) {
-  return plan_wgrad_grouped(items, n, false, table_host, table_bytes, workspace_bytes, grid_wgrad, grid_big, grid_reduce);
-}
-
-extern "C" int mxdet_conv2d_wgrad_grouped_plan_update(const mxdet_wgrad_item_t* items, int32_t n, const float* grad_arena,
-                                                      int64_t arena_elems, void* table_host, size_t table_bytes,
-                                                      size_t* workspace_bytes, int32_t* grid_wgrad, int32_t* grid_big,
-                                                      int32_t* grid_reduce) {
-  clear_error();
-  MXDET_REQUIRE(items && n > 0 && grad_arena && arena_elems > 0, MXDET_EINVAL,
-                "wgrad_grouped_plan_update: null pointer or empty group");
-  for (int i = 0; i < n; ++i) {
-    const mxdet_conv_desc_t& d = items[i].desc;
-    const long long nw = (long long)d.Cout * d.KH * d.KW * d.Cin;
-    MXDET_REQUIRE(items[i].dw >= grad_arena && items[i].dw + nw <= grad_arena + arena_elems, MXDET_EINVAL,
-                  "wgrad_grouped_plan_update: item %d: dw is not inside the gradient arena", i);
-    MXDET_REQUIRE(!items[i].db || (items[i].db >= grad_arena && items[i].db + d.Cout <= grad_arena + arena_elems),
-                  MXDET_EINVAL, "wgrad_grouped_plan_update: item %d: db is not inside the gradient arena", i);
-    MXDET_REQUIRE(((items[i].dw - grad_arena) & 3) == 0, MXDET_EINVAL,
-                  "wgrad_grouped_plan_update: item %d: dw is not 16-byte aligned inside the arena", i);
-  }
-  return plan_wgrad_grouped(items, n, true, table_host, table_bytes, workspace_bytes, grid_wgrad, grid_big, grid_reduce);
-}
-
-static int launch_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
-                                int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
-                                size_t workspace_needed, const WgradUpd* upd, mxdet_stream_t stream);
-
 extern "C" int mxdet_conv2d_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
                                           int32_t grid_reduce, void* workspace, size_t workspace_bytes,
                                           size_t workspace_needed, mxdet_stream_t stream) {
-  return launch_wgrad_grouped(table_dev, n, grid_wgrad, grid_big, grid_reduce, 7, workspace, workspace_bytes,
-                              workspace_needed, nullptr, stream);
-}
-
-extern "C" int mxdet_conv2d_wgrad_grouped_update(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
-                                                 int32_t grid_reduce, void* workspace, size_t workspace_bytes,
-                                                 size_t workspace_needed, const mxdet_sgd_arena_t* arena,
-                                                 mxdet_stream_t stream) {
-  clear_error();
-  MXDET_REQUIRE(arena && arena->grad && arena->w && arena->mom, MXDET_EINVAL, "wgrad_grouped_update: null arena pointer");
-  MXDET_REQUIRE(grid_reduce > 0, MXDET_EINVAL,
-                "wgrad_grouped_update: the table has no fold (plan it with mxdet_conv2d_wgrad_grouped_plan_update)");
-  WgradUpd u;
-  u.grad = arena->grad; u.w = arena->w; u.mom = arena->mom; u.wb = arena->w_bf16; u.lr_dev = arena->lr_dev;
-  u.lr = arena->lr; u.momentum = arena->momentum; u.wd = arena->wd; u.rescale = arena->rescale;
-  u.write_grad = arena->write_grad;
-  return launch_wgrad_grouped(table_dev, n, grid_wgrad, grid_big, grid_reduce, 7, workspace, workspace_bytes,
-                              workspace_needed, &u, stream);
+  return mxdet_conv2d_wgrad_grouped_parts(table_dev, n, grid_wgrad, grid_big, grid_reduce, 7, workspace, workspace_bytes,
+                                          workspace_needed, stream);
 }
 
 // parts: bit 0 = the three-tap kernel, bit 1 = the one-tap kernel (+ bias workgroups), bit 2 = the fold. The two tile
@@ -700,13 +618,6 @@ extern "C" int mxdet_conv2d_wgrad_grouped_update(const void* table_dev, int32_t 
 extern "C" int mxdet_conv2d_wgrad_grouped_parts(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
                                                 int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
                                                 size_t workspace_needed, mxdet_stream_t stream) {
-  return launch_wgrad_grouped(table_dev, n, grid_wgrad, grid_big, grid_reduce, parts, workspace, workspace_bytes,
-                              workspace_needed, nullptr, stream);
-}
-
-static int launch_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_wgrad, int32_t grid_big,
-                                int32_t grid_reduce, int32_t parts, void* workspace, size_t workspace_bytes,
-                                size_t workspace_needed, const WgradUpd* upd, mxdet_stream_t stream) {
   clear_error();
   if (!(parts & 1)) grid_big = 0;
   if (!(parts & 4)) grid_reduce = 0;
@@ -756,14 +667,9 @@ static int launch_wgrad_grouped(const void* table_dev, int32_t n, int32_t grid_w
                            (const WgradG*)table_dev, n, (unsigned char*)workspace);
     }
   }
-  if (grid_reduce > 0) {
-    if (upd)
-      hipLaunchKernelGGL((wgrad_reduce_grouped_kernel<true>), dim3((unsigned)grid_reduce), dim3(256), 0, s,
-                         (const WgradG*)table_dev, n, (const unsigned char*)workspace, *upd);
-    else
-      hipLaunchKernelGGL((wgrad_reduce_grouped_kernel<false>), dim3((unsigned)grid_reduce), dim3(256), 0, s,
-                         (const WgradG*)table_dev, n, (const unsigned char*)workspace, WgradUpd{});
-  }
+  if (grid_reduce > 0)
+    hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)grid_reduce), dim3(256), 0, s,
+                       (const WgradG*)table_dev, n, (const unsigned char*)workspace);
   return check_launch("conv2d_wgrad_grouped");
 }
 

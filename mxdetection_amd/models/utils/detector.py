@@ -33,11 +33,6 @@ class DetectorBase:
         self.bucket_merge = os.environ.get("MXDET_TUNE_BUCKETS", "123")
         self.branch = None
         self._upd = None          # (lr, momentum, wd) while a training step wants its buckets updated as they finish
-        # the grouped weight-gradient fold applies the update itself (single GPU): the gradient arena then holds gradients
-        # only if materialize_grads is set (forward_backward() without an update always writes them)
-        self.fuse_update = os.environ.get("MXDET_TUNE_FUSE_UPDATE", "1") == "1"
-        self.materialize_grads = False
-        self._covered = {}
         self._upd_done = []       # arena ranges already updated in this step
         self._tr_ranges = {}
         self._buckets = []        # (lo, hi) of every bucket exchanged in the captured step
@@ -289,20 +284,11 @@ class DetectorBase:
         bucket and go out first, on the same stream (the RPN head's, when they were not issued inside the branch)."""
         side_graph = (self._cap and self.dist is not None and hi > lo and self.ws.side is not None and self.ws.grouping
                       and bool(self.ws.pending) and os.environ.get("MXDET_TUNE_WGRAD_GRAPH", "1") == "1")
-        fused = False
         if not side_graph:
-            # single GPU, the step updates its buckets as they finish: the fold of the grouped weight-gradient launch applies
-            # the SGD-momentum step itself (the folded gradient is not written and read back; one launch less per bucket)
-            upd = None
-            if (self._upd is not None and self.dist is None and hi > lo and self.fuse_update and "sgd" not in _ABL
-                    and self.ws.fusable() and (pre is None or (pre.grouping and pre.fusable()))
-                    and self._bucket_covered(lo, hi, pre)):
-                upd = (self.arena,) + tuple(self._upd) + (1.0, self.materialize_grads)
-                fused = True
             if pre is not None:
                 pre.side = self.ws.side
-                pre.flush(update=upd)
-            self.ws.flush(update=upd)           # grouped mode: the bucket's recorded weight gradients go out now
+                pre.flush()
+            self.ws.flush()           # grouped mode: the bucket's recorded weight gradients go out now
             if self.dist is not None:
                 # the all-reduce is ordered on the main stream: wait for the side stream's weight gradients. Without an
                 # exchange the bucket's update follows its weight gradients ON the side stream and the main stream never
@@ -357,32 +343,16 @@ class DetectorBase:
             if hi > lo:
                 self._seen_buckets.add((lo, hi))
         if self._upd is not None and self.dist is None and hi > lo:
-            self._update_range(lo, hi, sgd=not fused)
+            self._update_range(lo, hi)
 
-    def _bucket_covered(self, lo, hi, pre=None):
-        """Do the weight gradients recorded for this bucket (self.ws, pre) produce the gradient of EVERY parameter tensor in
-        arena[lo:hi)? Only then may their fold stand in for the optimizer kernel over the range."""
-        have = set()
-        for w in ((pre, self.ws) if pre is not None else (self.ws,)):
-            for l, _x, _dy in w.pending:
-                have.add(l.wi)
-                if l.train_bias:
-                    have.add(l.bi)
-        key = (lo, hi, tuple(sorted(have)))
-        ok = self._covered.get(key)
-        if ok is None:
-            want = {i for i, e in enumerate(self.arena.entries) if lo <= e[2] < hi}
-            ok = self._covered[key] = (want == have)
-        return ok
-
-    def _update_range(self, lo, hi, sgd=True):
+    def _update_range(self, lo, hi):
         """SGD-momentum update + bf16 / transposed working copies of one finished bucket, on the weight-gradient stream:
         nothing issued so far in this step reads these parameters any more, so the update overlaps the rest of the
         backward pass instead of forming a serial tail after it (single-GPU path; with a gradient exchange the update
         follows the last all-reduce, see optimizer_step)."""
         ctx = self.ws.fork()
         with (ctx if ctx is not None else contextlib.nullcontext()):
-            self._apply_update(lo, hi, self._upd, 1.0, sgd=sgd)
+            self._apply_update(lo, hi, self._upd, 1.0)
         self._upd_done.append((lo, hi))
 
     def _transpose_table(self, lo, hi):
@@ -394,13 +364,12 @@ class DetectorBase:
             self._tr_ranges[key] = dense.make_transpose_table(pairs, self.device) if pairs else None
         return self._tr_ranges[key]
 
-    def _apply_update(self, lo, hi, hyper, rescale, sgd=True):
-        """SGD-momentum on arena[lo:hi] + refresh of the bf16 / transposed working copies of that range. sgd=False: the
-        weight-gradient fold has applied the step already (_reduce), only the transposed copies are refreshed."""
+    def _apply_update(self, lo, hi, hyper, rescale):
+        """SGD-momentum on arena[lo:hi] + refresh of the bf16 / transposed working copies of that range."""
         from ...ops import dense
         lr, momentum, wd = hyper
         a = self.arena
-        if sgd and "sgd" not in _ABL:
+        if "sgd" not in _ABL:
             dense.sgd_momentum_update(a.w[lo:hi], a.g[lo:hi], a.m[lo:hi], a.wb[lo:hi], lr, momentum, wd, rescale)
         table = self._transpose_table(lo, hi)
         if table is not None and "transpose" not in _ABL:

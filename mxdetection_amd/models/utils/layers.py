@@ -54,53 +54,33 @@ class Workspace:
     def defer(self, layer, x, dy):
         self.pending.append((layer, x, dy))
 
-    def _plan_key(self, items, fused):
-        return (bool(fused),) + tuple((id(l), x.data_ptr(), dy.data_ptr()) for l, x, dy in items)
-
-    def fusable(self):
-        """Can flush(update=...) let the fold apply the optimizer step to everything recorded so far? Needs the grouped
-        launch, and a plan: built now (eager) or cached from an eager pass (under capture no table can be uploaded)."""
-        if not self.grouping:
-            return False
-        if not self.pending:
-            return True
-        return (not torch.cuda.is_current_stream_capturing()) or self._plan_key(self.pending, True) in self.plans
-
-    def flush(self, update=None):
-        """Issue the recorded weight gradients (on the side stream if there is one). update = (arena, lr, momentum, wd,
-        rescale, write_grad): the fold of the grouped launch applies the SGD-momentum step to the recorded layers' parameters
-        (mxdet_conv2d_wgrad_grouped_update) instead of writing their gradients; the caller has checked fusable()."""
+    def flush(self):
+        """Issue the recorded weight gradients (on the side stream if there is one)."""
         if not self.pending:
             return
         items, self.pending = self.pending, []
         if "wgrad" in os.environ.get("MXDET_ABL_SKIP", ""):       # timing-only ablation, see detector._ABL
             return
-        key = self._plan_key(items, update is not None)
+        key = tuple((id(l), x.data_ptr(), dy.data_ptr()) for l, x, dy in items)
         plan = self.plans.get(key)
         capturing = torch.cuda.is_current_stream_capturing()
         if plan is None and not capturing:
             calls = [(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
                       l.arena.view(l.bi, "g") if l.train_bias else None, False) for l, x, dy in items]
-            plan = dense.GroupedWgrad(calls, self.device, update_arena=update[0].g if update is not None else None)
+            plan = dense.GroupedWgrad(calls, self.device)
             self.plans[key] = plan
             if self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
                 self._retired.append(self.gbuf)
                 self.gbuf = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device=self.device)
         ctx = self.fork()
         with (ctx if ctx is not None else contextlib.nullcontext()):
-            if update is not None:
-                if plan is None or self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
-                    raise RuntimeError("flush(update=...) without a plan: call fusable() first")
-                arena, lr, momentum, wd, rescale, write_grad = update
-                plan.launch_update(self.gbuf, arena.w, arena.m, arena.wb, lr, momentum, wd, rescale, write_grad)
-            elif plan is None or self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
+            if plan is None or self.gbuf is None or self.gbuf.numel() < plan.workspace_bytes:
                 # first seen under capture (no eager warm-up): a table cannot be uploaded now -- per-layer launches
                 for l, x, dy in items:
                     dense.conv2d_wgrad(x, dy, l.k, l.k, l.stride, l.pad, l.arena.view(l.wi, "g"),
                                        l.arena.view(l.bi, "g") if l.train_bias else None, False, self.get())
             else:
                 plan.launch(self.gbuf)
-
     def fork(self):
         if self.side is None:
             return None

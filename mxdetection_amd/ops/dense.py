@@ -216,12 +216,9 @@ class GroupedWgrad:
     (x, dy, KH, KW, stride, pad, dw, db, accumulate); the plan (device table, grids, workspace size) is built once, in
     eager mode, and stays valid while the tensors keep their addresses (e.g. under hipGraph replay)."""
 
-    def __init__(self, calls, device, update_arena=None):
-        """update_arena: the fp32 gradient arena tensor every dw / db is a view of -- the plan then routes every item through
-        the fold, which launch_update() makes apply the SGD-momentum step (mxdet_conv2d_wgrad_grouped_update)."""
+    def __init__(self, calls, device):
         lib = _lib.load()
         n = len(calls)
-        self.update_arena = update_arena
         items = (_lib.WgradItemT * n)()
         self.keep = calls                     # the tensors whose addresses the table holds
         self.flops = 0.0
@@ -237,13 +234,8 @@ class GroupedWgrad:
         nbytes = lib.mxdet_conv2d_wgrad_grouped_table_bytes(n)
         host = (C.c_ubyte * nbytes)()
         ws, gw, gb, gr = C.c_size_t(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        if update_arena is not None:
-            check(lib.mxdet_conv2d_wgrad_grouped_plan_update(items, n, ptr(update_arena), update_arena.numel(), host, nbytes,
-                                                             C.byref(ws), C.byref(gw), C.byref(gb), C.byref(gr)),
-                  "conv2d_wgrad_grouped_plan_update")
-        else:
-            check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gb),
-                                                      C.byref(gr)), "conv2d_wgrad_grouped_plan")
+        check(lib.mxdet_conv2d_wgrad_grouped_plan(items, n, host, nbytes, C.byref(ws), C.byref(gw), C.byref(gb),
+                                                  C.byref(gr)), "conv2d_wgrad_grouped_plan")
         self.grid_big = gb.value
         self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(device)
         self.n, self.grid_wgrad, self.grid_reduce, self.workspace_bytes = n, gw.value, gr.value, ws.value
@@ -252,23 +244,6 @@ class GroupedWgrad:
         check(_lib.load().mxdet_conv2d_wgrad_grouped(ptr(self.table), self.n, self.grid_wgrad, self.grid_big, self.grid_reduce,
                                                      ptr(workspace), workspace.numel() if workspace is not None else 0,
                                                      self.workspace_bytes, stream_ptr()), "conv2d_wgrad_grouped")
-
-
-    def launch_update(self, workspace, w, mom, w_bf16, lr, momentum, wd, rescale=1.0, write_grad=False):
-        """Tiles + a fold that applies the optimizer step to the parameter arenas (same offsets as the gradient arena given to
-        the constructor). lr: python float, or a 1-element fp32 device tensor read when the kernel runs."""
-        a = _lib.SgdArenaT()
-        a.grad, a.w, a.mom, a.w_bf16 = ptr(self.update_arena), ptr(w), ptr(mom), ptr(w_bf16)
-        if torch.is_tensor(lr):
-            a.lr_dev, a.lr = ptr(lr), 0.0
-        else:
-            a.lr_dev, a.lr = None, float(lr)
-        a.momentum, a.wd, a.rescale, a.write_grad = float(momentum), float(wd), float(rescale), int(bool(write_grad))
-        check(_lib.load().mxdet_conv2d_wgrad_grouped_update(ptr(self.table), self.n, self.grid_wgrad, self.grid_big,
-                                                            self.grid_reduce, ptr(workspace),
-                                                            workspace.numel() if workspace is not None else 0,
-                                                            self.workspace_bytes, C.byref(a), stream_ptr()),
-              "conv2d_wgrad_grouped_update")
 
 
 def filter_transpose(w, out=None):

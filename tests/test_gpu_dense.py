@@ -573,86 +573,3 @@ def test_relu_bitmask_forward_and_dgrad(hip):
         assert torch.equal(d_mask, d_bits)
         assert torch.all(d_bits[y <= 0] == 0)
 
-
-
-@pytest.mark.gpu
-def test_grouped_wgrad_fold_applies_the_update_bit_identical(hip, oracle):
-    """mxdet_conv2d_wgrad_grouped_update (the fold applies SGD-momentum to the parameter arenas) against the two-launch form
-    mxdet_conv2d_wgrad_grouped + mxdet_sgd_momentum_update on the same arenas: parameters, momentum and bf16 copies equal bit
-    for bit -- single-split items (forced through the fold), deep splits, a filter shared by two levels, bias gradients,
-    both tile kinds -- and the gradient arena is written only on request."""
-    import torch
-    from mxdetection_amd.ops import dense
-    rng = np.random.default_rng(44)
-    # (N, H, W, Cin, Cout, K, stride, pad, bias)
-    cases = [(2, 25, 42, 256, 256, 3, 1, 1, True), (2, 13, 21, 512, 448, 1, 1, 0, True), (1, 26, 44, 256, 512, 3, 2, 1, False),
-             (300, 1, 1, 1024, 256, 1, 1, 0, True), (1, 4, 5, 64, 64, 1, 1, 0, True), (2, 50, 84, 128, 128, 3, 1, 1, False)]
-    shared = [(2, 13, 21), (2, 7, 11)]
-    sizes = []
-    for N, H, W, Cin, Cout, K, s, pd, bias in cases:
-        sizes.append(Cout * K * K * Cin)
-        sizes.append(Cout if bias else 0)
-    sizes += [256 * 9 * 256, 256]
-    offs, total = [], 0
-    for n in sizes:
-        offs.append(total)
-        total += (n + 63) // 64 * 64
-
-    def build():
-        g = torch.zeros((total,), device="cuda")
-        w = torch.from_numpy(rng0.standard_normal(total).astype(np.float32)).cuda()
-        m = torch.from_numpy((0.1 * rng0.standard_normal(total)).astype(np.float32)).cuda()
-        wb = torch.zeros((total,), dtype=torch.bfloat16, device="cuda")
-        return g, w, m, wb
-    ops = []
-    for N, H, W, Cin, Cout, K, s, pd, bias in cases:
-        Ho, Wo = (H + 2 * pd - K) // s + 1, (W + 2 * pd - K) // s + 1
-        ops.append((_t(_bf(rng, (N, H, W, Cin), 1.0, oracle), torch.bfloat16), _t(_bf(rng, (N, Ho, Wo, Cout), 1.0, oracle), torch.bfloat16)))
-    sh = [(_t(_bf(rng, (n, h, w, 256), 1.0, oracle), torch.bfloat16), _t(_bf(rng, (n, h, w, 256), 1.0, oracle), torch.bfloat16))
-          for n, h, w in shared]
-
-    def calls_for(g):
-        calls = []
-        for k, ((N, H, W, Cin, Cout, K, s, pd, bias), (x, dy)) in enumerate(zip(cases, ops)):
-            dw = g[offs[2 * k]:offs[2 * k] + sizes[2 * k]].view(Cout, K, K, Cin)
-            db = g[offs[2 * k + 1]:offs[2 * k + 1] + Cout] if bias else None
-            calls.append((x, dy, K, K, s, pd, dw, db, False))
-        dw_s = g[offs[-2]:offs[-2] + sizes[-2]].view(256, 3, 3, 256)
-        db_s = g[offs[-1]:offs[-1] + 256]
-        for x, dy in sh:
-            calls.append((x, dy, 3, 3, 1, 1, dw_s, db_s, False))
-        return calls
-    lr, mom, wd, rescale = 0.01, 0.9, 1e-4, 0.5
-    res = []
-    for mode in ("two launches", "fused", "fused + gradients", "fused, lr from device memory"):
-        rng0 = np.random.default_rng(7)
-        g, w, m, wb = build()
-        if mode == "two launches":
-            plan = dense.GroupedWgrad(calls_for(g), "cuda")
-            ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
-            plan.launch(ws)
-            dense.sgd_momentum_update(w, g, m, wb, lr, mom, wd, rescale)
-        else:
-            plan = dense.GroupedWgrad(calls_for(g), "cuda", update_arena=g)
-            assert plan.grid_reduce > 0 and plan.grid_big > 0 and plan.grid_wgrad > 0
-            ws = torch.empty((max(plan.workspace_bytes, 256),), dtype=torch.uint8, device="cuda")
-            lr_arg = torch.tensor([lr], device="cuda") if "device" in mode else lr
-            plan.launch_update(ws, w, m, wb, lr_arg, mom, wd, rescale, write_grad="gradients" in mode)
-        torch.cuda.synchronize()
-        res.append((g.clone(), w.clone(), m.clone(), wb.clone()))
-    g0, w0, m0, wb0 = res[0]
-    live = torch.zeros((total,), dtype=torch.bool, device="cuda")          # alignment gaps between tensors see no update when fused
-    for o, n in zip(offs, sizes):
-        live[o:o + n] = True
-    assert g0[live].abs().sum().item() > 0
-    for k in (1, 2, 3):
-        g, w, m, wb = res[k]
-        assert torch.equal(w[live], w0[live]) and torch.equal(m[live], m0[live])
-        assert torch.equal(wb[live].view(torch.int16), wb0[live].view(torch.int16))
-    assert res[1][0].abs().sum().item() == 0                    # the folded gradient was not written ...
-    assert torch.equal(res[2][0][live], g0[live])                # ... unless asked for, and then it is the same gradient
-    # a dw outside the arena is refused at plan time
-    stray = torch.zeros((64, 1, 1, 64), device="cuda")
-    x, dy = ops[4]
-    with pytest.raises(RuntimeError, match="not inside the gradient arena"):
-        dense.GroupedWgrad([(x, dy, 1, 1, 1, 0, stray, None, False)], "cuda", update_arena=res[0][0])

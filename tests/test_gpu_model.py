@@ -360,39 +360,3 @@ def test_predict_between_replays_leaves_the_captured_step_intact(hip):
     m.capture(image, gt, im_info, lr=0.001)
     with pytest.raises(RuntimeError, match="captured training step"):
         m.predict(image[:, :, :192, :256].contiguous(), im_info)
-
-
-@pytest.mark.gpu
-def test_update_inside_the_weight_gradient_fold_takes_the_same_steps(hip):
-    """Single-GPU training lets the fold of each bucket's grouped weight-gradient launch apply the SGD-momentum step
-    (DetectorBase.fuse_update). Two eager steps and two replayed steps, with and without it: parameters, momentum and bf16
-    copies equal bit for bit; without materialize_grads the gradient arena stays untouched, with it it holds the gradients."""
-    import torch
-    from mxdetection_amd.models import FasterRCNN
-    N, H, W = 2, 256, 320
-    image, gt, im_info = _inputs(N, H, W, seed=5)
-    out = {}
-    for mode in ("plain", "fused", "fused+grads"):
-        m = FasterRCNN("cuda", seed=7, pre_nms_top_n=1000, post_nms_top_n=1000)
-        m.fuse_update = mode != "plain"
-        m.materialize_grads = mode == "fused+grads"
-        m.enable_wgrad_stream()
-        m.enable_branch_stream()
-        m.enable_grouped_wgrad()
-        for step in (0, 1):
-            m.train_step(image, gt, im_info, step=step, lr=0.002)
-        torch.cuda.synchronize()
-        eager = (m.arena.w.clone(), m.arena.m.clone(), m.arena.wb.clone().view(torch.int16))
-        g_eager = m.arena.g.clone()
-        m.capture(image, gt, im_info, lr=0.002, image_offset=0, warmup=1)
-        for step in (2, 3):
-            m.replay(image, gt, im_info, step)
-        torch.cuda.synchronize()
-        out[mode] = (eager, (m.arena.w.clone(), m.arena.m.clone(), m.arena.wb.clone().view(torch.int16)), g_eager)
-    for mode in ("fused", "fused+grads"):
-        for phase in (0, 1):
-            for a, b in zip(out["plain"][phase], out[mode][phase]):
-                assert torch.equal(a, b), (mode, phase)
-    assert not torch.equal(out["plain"][0][0], out["plain"][1][0])          # the replayed steps did move the weights
-    assert out["fused"][2].abs().sum().item() == 0                           # gradients were consumed in the fold
-    assert torch.equal(out["fused+grads"][2], out["plain"][2])               # ... or written as well, on request
