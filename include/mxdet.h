@@ -349,16 +349,6 @@ int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t* x, const 
                            const uint16_t* w2, const float* bias2, int32_t cout2, int32_t relu2,
                            const uint16_t* residual2, uint16_t* y2, const uint16_t* w3, const float* bias3,
                            int32_t cout3, int32_t relu3, uint16_t* y3, mxdet_stream_t stream);
-/* The same chain for a TRAINABLE bottleneck with 128 mid channels (models/backbones, /root/reference/README.md:27: the stride-1
- * blocks of ResNet stage C3): d describes the 3x3 (stride 1, pad 1, Cin % 64 == 0, Cout == 128), w2 is [cout2][1][1][128]
- * with cout2 == 512. Backward needs what two launches would have stored, so this launch stores it too: y_mid
- * [N, Ho, Wo, 128] = act(conv3x3 + bias) and, if not NULL, its 1-bit ReLU mask mid_bits [N, Ho, Wo, 16] and the mask
- * y2_bits [N, Ho, Wo, cout2 / 8] of the output (layout as mxdet_conv_desc_t.relu_bits). Saves conv3's launch and its read
- * of y_mid; bit-identical to mxdet_conv2d_fwd twice. */
-int mxdet_conv2d_fwd_chain_train(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
-                                 uint16_t* y_mid, uint8_t* mid_bits, const uint16_t* w2, const float* bias2,
-                                 int32_t cout2, int32_t relu2, const uint16_t* residual2, uint16_t* y2, uint8_t* y2_bits,
-                                 mxdet_stream_t stream);
 /* Forward with the reduction split over `ksplit` ranges of 64-channel slices, for 1x1 / stride-1 layers with a long
  * reduction on few rows (fully connected layers on pooled rois): raw fp32 tiles in the caller's workspace, folded in
  * split order (deterministic) with bias / residual / ReLU by a second kernel. Last-bit different from mxdet_conv2d_fwd

@@ -126,8 +126,6 @@ SIGNATURES = {
     "mxdet_conv2d_fwd": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mxdet_conv2d_fwd_chain": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                        c_i32, c_vp, c_vp]),
-    "mxdet_conv2d_fwd_chain_train": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp,
-                                             c_vp]),
     "mxdet_conv2d_fwd_splitk_workspace_bytes": (c_sz, [P(ConvDescT), c_i32]),
     "mxdet_conv2d_fwd_splitk": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "mxdet_conv2d_dgrad": (c_i32, [P(ConvDescT), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -172,7 +170,7 @@ DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit",
                  "mxdet_debug_set_tuning")
 TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "T3_ENABLE": 6,
                "T3_TARGET": 7, "T3_MINSTEPS": 8, "T3_NS": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14,
-               "T128W": 15, "T3_MIX": 16, "SPLITK_TILE": 17, "CHAIN_TILE": 18}
+               "T128W": 15, "T3_MIX": 16, "SPLITK_TILE": 17}
 
 _lib = None
 

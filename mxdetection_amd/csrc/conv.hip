@@ -64,10 +64,6 @@ struct ConvP {
   const float* chain3_bias;    // [64] or null
   uint16_t* chain3_y;          // [M][64]
   int chain3_relu;
-  // trainable blocks (BN == 128, mxdet_conv2d_fwd_chain_train): the intermediate map and both 1-bit ReLU masks are stored too
-  uint16_t* chain_mid_y;           // [M][BN] or null: relu(conv3x3 + bias) as the unchained layer stores it
-  unsigned char* chain_mid_bits;   // [M][BN / 8] or null
-  unsigned char* chain_bits;       // [M][CHAIN / 8] or null: mask of the chained output
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -115,14 +111,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   constexpr int MAIN_BYTES = NBUF * STAGE * 2;
   // CHAIN > 0: a 1x1 convolution to CHAIN columns follows in the same workgroup (see after the K loop); its whole filter
   // (CHAIN x 64 bf16) sits behind the ring / epilogue area for the workgroup's life
-  static_assert(CHAIN == 0 || (TAPS == 9 && !DGRAD && WN == 1 && (BN == 64 || BN == 128) && CHAIN % (8 * NW) == 0 &&
-                               CHAIN % BN == 0),
-                "chain: forward 3x3 whose waves own all mid channels (64 or 128) of their rows");
-  // 64 mid channels: the chained filter (CHAIN x 64) sits in LDS; 128: 128 KiB would not fit -- its fragments come from L2
-  constexpr bool CHAIN_LDS = CHAIN > 0 && BN == 64;
-  constexpr int KH2 = BN / 32;                        // 32-deep halves of the chained reduction
+  static_assert(CHAIN == 0 || (TAPS == 9 && !DGRAD && WN == 1 && BN == 64 && CHAIN % (8 * NW) == 0),
+                "chain: forward 3x3 whose waves own all 64 mid channels of their rows");
   constexpr int CHAIN_OFF = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
-  constexpr int SMEM_BYTES = CHAIN_OFF + (CHAIN_LDS ? CHAIN * 128 : 0);
+  constexpr int SMEM_BYTES = CHAIN_OFF + CHAIN * 128;
   __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
   uint16_t* smem = (uint16_t*)smem_raw;
 
@@ -223,7 +215,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     for (int s0 = 0; s0 < NS - 1; ++s0)
       issue_b(s0, s0 % TAPS, (sl_begin + s0 / TAPS) * 64, s0 < (sl_end - sl_begin) * TAPS);
   }
-  if constexpr (CHAIN_LDS) {
+  if constexpr (CHAIN > 0) {
     // the chained filter: CHAIN rows x 64 channels in the B-stage image (8 rows per piece), older than every ring piece of
     // this wave, so the K loop's first counted wait covers it
     const __amdgpu_buffer_rsrc_t rsrc_c = make_rsrc(p.chain_w, 2u * (unsigned)CHAIN * 64u);
@@ -592,7 +584,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   // rows read back in the A-fragment layout, + bias, ReLU, rounded to bf16 exactly as the unfused layer stores them; then
   // per 64-column chunk 2 * MT * NT MFMAs against the filter image in LDS (two 32-deep halves in the order of the
   // stand-alone 1x1 kernel: bit-identical sums) and the ordinary epilogue on the chunk.
-  bf16x8_t af2[CHAIN > 0 ? MT : 1][CHAIN > 0 ? KH2 : 1];
+  bf16x8_t af2[CHAIN > 0 ? MT : 1][2];
   if constexpr (CHAIN > 0) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -602,7 +594,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         for (int r = 0; r < 4; ++r)
           ep[(i * 16 + fq * 4 + r) * EP_STRIDE + j * 16 + frow] = acc[i][j][r];
 #pragma unroll
-    for (int hf = 0; hf < KH2; ++hf) {
+    for (int hf = 0; hf < 2; ++hf) {
       float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
       if (p.bias) {
         c0 = *(const float4*)(p.bias + hf * 32 + fq * 8);
@@ -623,25 +615,6 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         o.z = pack_bf16x2(v[4], v[5]);
         o.w = pack_bf16x2(v[6], v[7]);
         af2[i][hf] = __builtin_bit_cast(bf16x8_t, o);
-        if (p.chain_mid_y != nullptr) {
-          // trainable block: backward needs the intermediate map (weight gradient of the chained layer) and its mask
-          const int m = m0 + wm * WTM + i * 16 + frow;
-          if (m < p.M) {
-            const size_t e = (size_t)m * BN + hf * 32 + fq * 8;
-            *(uint4*)(p.chain_mid_y + e) = o;
-            if (p.chain_mid_bits != nullptr) {
-              const unsigned w4[4] = {o.x, o.y, o.z, o.w};
-              unsigned mb = 0;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const unsigned lo = w4[k] & 0xffffu, hi = w4[k] >> 16;
-                mb |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * k);
-                mb |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * k + 1);
-              }
-              p.chain_mid_bits[e >> 3] = (unsigned char)mb;
-            }
-          }
-        }
       }
     }
   }
@@ -652,7 +625,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
   // the loop then runs the ordinary epilogue on that accumulator (K order = chunk, half: that of the stand-alone kernel).
   static_assert(CHAIN == 0 || MT == 2, "chain: one epilogue half covers the wave's rows");
   constexpr int NCH = CHAIN > 0 ? CHAIN / BN : 1;
-  const bool c3 = CHAIN_LDS && p.chain3_w != nullptr;
+  const bool c3 = CHAIN > 0 && p.chain3_w != nullptr;
   f32x4_t acc3[CHAIN > 0 ? MT : 1][CHAIN > 0 ? NT : 1];
   if constexpr (CHAIN > 0) {
 #pragma unroll
@@ -689,42 +662,21 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
     }
   }
   if (CHAIN > 0 && !last3) {
+    const uint16_t* wl = (const uint16_t*)(smem_raw + CHAIN_OFF);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if constexpr (CHAIN_LDS) {
-      const uint16_t* wl = (const uint16_t*)(smem_raw + CHAIN_OFF);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        bf16x8_t bw[NT];
+    for (int hf = 0; hf < 2; ++hf) {
+      bf16x8_t bw[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bw[j] = *(const bf16x8_t*)(wl + lds_off(n0c + j * 16 + frow, hf * 4 + fq));
+      for (int j = 0; j < NT; ++j) bw[j] = *(const bf16x8_t*)(wl + lds_off(n0c + j * 16 + frow, hf * 4 + fq));
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[i][hf], bw[j], acc[i][j], 0, 0, 0);
-      }
-    } else {
-      // filter fragments of this chunk straight from L2 ([CHAIN][BN] row-major: a fragment row is 64 contiguous bytes), one
-      // 32-deep half ahead of the MFMAs that use them; halves in the order of the stand-alone 1x1 kernel (bit-identical sums)
-      const uint16_t* wg = p.chain_w + (size_t)(n0c + frow) * BN + fq * 8;
-      bf16x8_t bw[2][NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bw[0][j] = *(const bf16x8_t*)(wg + (size_t)j * 16 * BN);
-#pragma unroll
-      for (int hf = 0; hf < KH2; ++hf) {
-        if (hf + 1 < KH2) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bw[(hf + 1) & 1][j] = *(const bf16x8_t*)(wg + (size_t)j * 16 * BN + (hf + 1) * 32);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[i][hf], bw[hf & 1][j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[i][hf], bw[j], acc[i][j], 0, 0, 0);
     }
   }
   // bias: one pair of loads per lane for the whole epilogue (the column does not depend on the pass)
@@ -847,8 +799,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
         // (this pass's fp32 rows have been read: the bf16 row takes the first 128 bytes of the same staging row)
         if (c3 && !last3) *(uint4*)((unsigned char*)ep + row * (EP_STRIDE * 4) + ((cg ^ (row & 7)) << 4)) = o;
       }
-      unsigned char* const e_bits = CHAIN > 0 ? (last3 ? nullptr : p.chain_bits) : p.bits_out;
-      if (e_bits && oks[ps]) {
+      if (CHAIN == 0 && p.bits_out && oks[ps]) {
         // the mask of the STORED values: bf16 > 0 <=> sign clear and magnitude non-zero (as the 16-bit mask test reads it)
         const unsigned w4[4] = {o.x, o.y, o.z, o.w};
         unsigned mb = 0;
@@ -858,7 +809,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvP& p, int bid, const i
           mb |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * k);
           mb |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * k + 1);
         }
-        e_bits[(pixs[ps] * e_ncols + col) >> 3] = (unsigned char)mb;
+        p.bits_out[(pixs[ps] * e_ncols + col) >> 3] = (unsigned char)mb;
       }
     }
   }
@@ -895,14 +846,6 @@ template <int BM, int BN, int WM, int WN, int NS, bool DGRAD, bool PAR = false, 
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_igemm_kernel(ConvP p) {
   conv_igemm_tile<BM, BN, WM, WN, NS, DGRAD, PAR, TAPS, CHAIN>(p, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// the trainable chain (mxdet_conv2d_fwd_chain_train): capped at 256 registers so that LDS (48 KiB), not registers, sets the
-// number of workgroups per CU
-template <int BM, int WM>
-__global__ void __launch_bounds__(64 * WM) __attribute__((amdgpu_waves_per_eu(2)))
-conv_chain_train_kernel(ConvP p) {
-  conv_igemm_tile<BM, 128, WM, 1, 2, false, false, 9, 512>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped form: independent convolutions that share one tile configuration (the 3x3 of every pyramid level of an RPN
@@ -982,8 +925,6 @@ static int launch(ConvP& p, hipStream_t s) {
     case 41: return MXDET_FORCE_ST(64, 128, 2, 2, 2);
     case 45: return MXDET_FORCE_ST(128, 128, 2, 2, 2);
     case 46: return MXDET_FORCE_ST(128, 64, 4, 1, 2);
-    case 47: return MXDET_FORCE_ST(64, 128, 2, 1, 2);             // two waves, each 32 rows x all 128 columns
-    case 48: return MXDET_FORCE_ST(128, 128, 4, 1, 2);            // four waves, each 32 rows x all 128 columns
     case 49: return MXDET_FORCE_ST(128, 128, 2, 4, 2);            // 8 waves, 64x32 per wave
     default: break;
   }
@@ -1142,51 +1083,6 @@ extern "C" int mxdet_conv2d_fwd_chain(const mxdet_conv_desc_t* d, const uint16_t
     p.chain3_w = w3; p.chain3_bias = bias3; p.chain3_y = y3; p.chain3_relu = relu3;
   }
   return launch_cfg<128, 64, 4, 1, 2, false, false, 9, 256>(p, as_stream(stream));
-}
-
-// The same chain for a TRAINABLE bottleneck with 128 mid channels (C3): conv2 (3x3, 128 -> 128) + ReLU and conv3 (1x1, 128 -> 512)
-// + shortcut + ReLU in one launch. Backward needs what the two launches would have stored, so the launch stores it too: the
-// intermediate map y_mid (weight gradient of conv3) with its 1-bit ReLU mask (data gradient of conv2), and the 1-bit mask of
-// the block output. What is saved is conv3's own launch and its read of y_mid through L2 -> LDS; the 512 x 128 filter does not
-// fit LDS beside the ring, its fragments come from L2 (64 contiguous bytes per fragment row). Bit-identical to the two
-// launches (same reduction order in both convolutions).
-extern "C" int mxdet_conv2d_fwd_chain_train(const mxdet_conv_desc_t* d, const uint16_t* x, const uint16_t* w, const float* bias,
-                                            uint16_t* y_mid, uint8_t* mid_bits, const uint16_t* w2, const float* bias2,
-                                            int32_t cout2, int32_t relu2, const uint16_t* residual2, uint16_t* y2,
-                                            uint8_t* y2_bits, mxdet_stream_t stream) {
-  clear_error();
-  int rc = validate(d, "conv2d_fwd_chain_train");
-  if (rc) return rc;
-  MXDET_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, MXDET_ESHAPE,
-                "conv2d_fwd_chain_train: the first convolution must be 3x3, stride 1, pad 1");
-  MXDET_REQUIRE(d->Cin % 64 == 0 && d->Cout == 128 && cout2 == 512, MXDET_ESHAPE,
-                "conv2d_fwd_chain_train: Cin %d must be a multiple of 64, Cout %d must be 128 and cout2 %d must be 512", d->Cin,
-                d->Cout, cout2);
-  MXDET_REQUIRE(!d->res_upsample && !d->relu_bits, MXDET_EINVAL,
-                "conv2d_fwd_chain_train: no upsampled residual; the masks are the mid_bits / y2_bits arguments");
-  MXDET_REQUIRE(x && w && w2 && y2 && y_mid, MXDET_EINVAL, "conv2d_fwd_chain_train: null pointer");
-  MXDET_REQUIRE((long long)d->N * d->Ho * d->Wo * cout2 < (1ll << 31), MXDET_ESHAPE,
-                "conv2d_fwd_chain_train: output exceeds 2^31");
-  ConvP p;
-  memset(&p, 0, sizeof(p));
-  p.x = x; p.w = w; p.bias = bias; p.y = nullptr;
-  p.N = d->N; p.Hs = d->H; p.Ws = d->W; p.C = d->Cin;
-  p.Hd = d->Ho; p.Wd = d->Wo; p.Ncols = d->Cout;
-  p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1;
-  p.relu = d->relu;
-  p.M = d->N * d->Ho * d->Wo;
-  p.pf = d->prefetch; p.pf_bytes = d->prefetch ? d->prefetch_bytes : 0;
-  p.chain_w = w2; p.chain_bias = bias2; p.chain_res = residual2; p.chain_y = y2; p.chain_relu = relu2;
-  p.chain_mid_y = y_mid; p.chain_mid_bits = mid_bits; p.chain_bits = y2_bits;
-  const bool wide = tuning(MXDET_TUNE_CHAIN_TILE) == 1;
-  const int BMc = wide ? 128 : 64;
-  p.tiles_m = ceil_div(p.M, BMc);
-  p.tiles_n = 1;
-  if (wide)
-    hipLaunchKernelGGL((conv_chain_train_kernel<128, 4>), dim3((unsigned)p.tiles_m), dim3(256), 0, as_stream(stream), p);
-  else
-    hipLaunchKernelGGL((conv_chain_train_kernel<64, 2>), dim3((unsigned)p.tiles_m), dim3(128), 0, as_stream(stream), p);
-  return check_launch("conv2d_fwd_chain_train");
 }
 
 // ---- split-K forward for long reductions on few rows (FC6: 1,024 rois x 12,544 features x 1,024 outputs) ----------------

@@ -89,19 +89,6 @@ def conv2d_forward_chain(x, w, bias, w2, bias2=None, residual2=None, relu=True, 
     return out if w3 is None else (out, out3)
 
 
-def conv2d_forward_chain_train(x, w, bias, w2, bias2, residual2, mid, out, mid_bits=None, out_bits=None, relu=True,
-                               relu2=True, prefetch=None):
-    """Trainable form of the chain (3x3 with 128 mid channels + 1x1 to 512): mid = relu?(conv(x, w) + bias) and its 1-bit mask
-    are stored as two launches would store them, out = relu2?(mid * w2 + bias2 + residual2) with its mask
-    (mxdet_conv2d_fwd_chain_train)."""
-    N, H, W, Cin = x.shape
-    d = conv_desc(N, H, W, Cin, w.shape[0], 3, 3, 1, 1, relu, False, prefetch=prefetch)
-    check(_lib.load().mxdet_conv2d_fwd_chain_train(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(mid), ptr(mid_bits), ptr(w2),
-                                                   ptr(bias2), w2.shape[0], int(relu2), ptr(residual2), ptr(out),
-                                                   ptr(out_bits), stream_ptr()), "conv2d_fwd_chain_train")
-    return out
-
-
 def conv2d_dgrad(dy, wt, x_shape, KH, KW, stride=1, pad=0, residual=None, relu_mask=None, accumulate=False, out=None,
                  prefetch=None, relu_bits=None):
     """wt: [Cin,KH,KW,Cout] (filter_transpose of the forward filter). relu_bits: the 1-bit form of relu_mask
