@@ -13,6 +13,7 @@ from .layers import ParamArena, Workspace
 # TIMING-ONLY ablations (tools/ablate_step.sh): MXDET_ABL_SKIP=front,sgd,transpose,wgrad leaves the named component out of the
 # replayed step -- results are wrong, only the step time means anything (the marginal cost of a component in the overlapped
 # schedule, which the sum of its kernel durations overstates). Never set outside that tool.
+_PROBE_STREAMS = []          # candidate streams of DetectorBase._stream_clear_of_the_exchange
 _ABL = frozenset(t for t in os.environ.get("MXDET_ABL_SKIP", "").split(",") if t)
 
 class DetectorBase:
@@ -475,6 +476,9 @@ class DetectorBase:
             torch.cuda.synchronize()
             self._tail_event = GraphEvent()
             fstream = self.branch if self.branch is not None else torch.cuda.Stream()
+            if (self.dist is not None and getattr(self.reducer, "comm", None) is not None
+                    and os.environ.get("MXDET_TUNE_FRONT_PROBE", "1") == "1"):
+                fstream = self._stream_clear_of_the_exchange(fstream)
             self._front = {"graphs": [], "segments": [], "losses": [], "stream": fstream, "count": 0,
                            "ready": [torch.cuda.Event(), torch.cuda.Event()], "pool": torch.cuda.graph_pool_handle()}
         side = torch.cuda.Stream()
@@ -547,6 +551,62 @@ class DetectorBase:
                     self._apply_update(lo, hi, self._cap_opt, 1.0 / self.world)
                     g.capture_end()
                 marker[1] = g
+
+    def _stream_clear_of_the_exchange(self, preferred, tries=4):
+        """A stream on which work is NOT held up while an all-reduce waits for its bucket's weight gradients.
+
+        HIP multiplexes streams onto a few hardware queues (four), in order of first use, and a stream that waits for an
+        event holds up every stream sharing its queue. During the weight-gradient tail of a step the communicator (its own
+        stream and RCCL's internal ones) has such a wait pending most of the time; the next step's front end has to run
+        beside that tail, so its stream must not share a queue with any of them (measured at world size 1: on the branch
+        stream the front end started only after the step's last all-reduce, and the pipeline's gain was lost). Which queue a
+        stream got cannot be asked, so it is measured: a long kernel on the weight-gradient stream, ONE all-reduce of a
+        scratch tensor behind it (every rank issues the same single collective), a tiny kernel on each candidate; candidates
+        whose kernel has finished while the long kernel still runs are clear. Returns `preferred` if it is clear, else the
+        first clear candidate, else `preferred`."""
+        import time
+        comm = self.reducer.comm
+        dev = self.arena.g.device
+        tries = int(os.environ.get("MXDET_TUNE_FRONT_PROBE_TRIES", tries))
+        while len(_PROBE_STREAMS) < tries:             # one set per process: every model's probe tries the same streams
+            _PROBE_STREAMS.append(torch.cuda.Stream())
+        cands = [preferred] + _PROBE_STREAMS[:tries]
+        tiny = torch.zeros((64,), device=dev)
+        scratch = torch.zeros((64,), device=dev)
+        big = torch.empty((1 << 27,), device=dev)                    # 512 MiB: one pass ~0.2 ms
+        wstream = self.ws.side if self.ws.side is not None else torch.cuda.Stream()
+        for s_ in cands + [wstream]:                                  # first use of every stream: queues are bound now
+            with torch.cuda.stream(s_):
+                tiny.add_(0.0)
+        torch.cuda.synchronize()
+        done_long = torch.cuda.Event()
+        with torch.cuda.stream(wstream):
+            for _ in range(60):                                       # ~10 ms of work in front of the collective
+                big.add_(1.0)
+            done_long.record()
+            ticket = comm.allreduce(scratch)                          # waits behind the long kernels: the pending wait
+        evs = []
+        for c in cands:
+            e = torch.cuda.Event()
+            with torch.cuda.stream(c):
+                tiny.add_(0.0)
+                e.record()
+            evs.append(e)
+        clear = [False] * len(cands)
+        t0 = time.perf_counter()
+        while not done_long.query() and time.perf_counter() - t0 < 2.0:
+            for i, e in enumerate(evs):
+                clear[i] = clear[i] or e.query()
+            if all(clear):
+                break
+        ticket.wait()
+        torch.cuda.synchronize()
+        del big
+        self.front_stream_probe = clear
+        for c, ok in zip(cands, clear):
+            if ok:
+                return c
+        return preferred
 
     def _mark_tail(self):
         """Called by forward_backward where the data-gradient chain has ended and only the last bucket's weight gradients,

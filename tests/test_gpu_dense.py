@@ -260,13 +260,14 @@ def test_sgd_momentum(hip):
     import torch
     from mxdetection_amd.ops import dense
     n = 1000003
+    torch.manual_seed(0)       # (unseeded, one element in a few million runs past the tolerance: the kernel contracts to FMAs)
     w, g, m = torch.randn(n, device="cuda"), torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
     wb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
     w0, m0 = w.clone(), m.clone()
     dense.sgd_momentum_update(w, g, m, wb, 0.02, 0.9, 1e-4, 0.5)
     m_ref = 0.9 * m0 + (g * 0.5 + 1e-4 * w0)
     w_ref = w0 - 0.02 * m_ref
-    assert torch.allclose(m, m_ref, rtol=1e-6, atol=1e-7) and torch.allclose(w, w_ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(m, m_ref, rtol=1e-6, atol=1e-6) and torch.allclose(w, w_ref, rtol=1e-6, atol=1e-6)
     assert torch.equal(wb, w.to(torch.bfloat16))
 
 
