@@ -201,6 +201,10 @@ def test_gradient_exchange_path_matches_single_gpu_step(hip):
         m.capture(image, gt, im_info, lr=lr, image_offset=0, warmup=1)   # the warm-up leaves weights / momentum alone
         losses = torch.cat(m.replay(image, gt, im_info, 1)).clone()
         torch.cuda.synchronize()
+        if parallel and m.comm is not None:
+            # the front end's stream was chosen by measurement (hardware-queue sharing with the communicator): the probe ran
+            # over the branch stream + spare streams and found at least one of them clear of the all-reduce's pending wait
+            assert len(m.front_stream_probe) >= 2 and any(m.front_stream_probe), m.front_stream_probe
         return w0, m.arena.w.clone(), losses, m.arena.wb.float().clone()
 
     w0, w_single, l_single, wb_single = one_step(False)
