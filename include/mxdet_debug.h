@@ -29,7 +29,7 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_WG_MAXSTEPS 5  /* grouped wgrad: most steps per workgroup (default 128) */
 #define MXDET_TUNE_T3_ENABLE 6    /* wgrad: 1 = 3x3 / stride 1 / pad 1 layers use the three-tap tile (wgrad3_tile.h; default 1) */
 #define MXDET_TUNE_T3_TARGET 7    /* ... workgroups of that kernel per group aimed for (default 1536) */
-#define MXDET_TUNE_T3_MINSTEPS 8  /* ... fewest 64-pixel steps per workgroup (default 16) */
+#define MXDET_TUNE_T3_MINSTEPS 8  /* ... fewest 64-pixel steps per workgroup (default 32: neutral for the two large groups of the single-GPU step, +1.9 % for the five smaller ones of the exchange schedule) */
 #define MXDET_TUNE_T3_NS 9        /* ... LDS-DMA ring depth, 2 or 3 (default 2) */
 #define MXDET_TUNE_TAIL 10        /* conv: tiles of the rows left over by the 256x256 rounds: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
 #define MXDET_TUNE_WG_NS 11       /* grouped wgrad (128x128 tiles): LDS-DMA ring depth 2, 3 or 4 */
