@@ -41,7 +41,8 @@ int mxdet_debug_preprocess_direct(int32_t on);
 #define MXDET_TUNE_T3_MIX 16    /* grouped wgrad: three-tap and one-tap tiles in ONE grid (0 = two launches; 1 = one-tap ring of 3
                                     stages inside the three-tap kernel's LDS; 2 = ring of 2; default 1) */
 #define MXDET_TUNE_SPLITK_TILE 17 /* mxdet_conv2d_fwd_splitk: 0 = 64x64 tiles, 1 = 128x128 (four waves), 2 = 128x128 (eight waves) */
-#define MXDET_TUNE_COUNT 18
+#define MXDET_TUNE_T3_PER_ITEM 18  /* grouped wgrad, three-tap tiles: at most this many workgroups per 3x3 layer of the group (0 = no cap; default 192) */
+#define MXDET_TUNE_COUNT 19
 int mxdet_debug_set_tuning(int32_t which, int64_t value);
 
 #ifdef __cplusplus

@@ -170,7 +170,7 @@ DEBUG_SYMBOLS = ("mxdet_debug_force_conv_cfg", "mxdet_debug_force_wgrad_ksplit",
                  "mxdet_debug_set_tuning")
 TUNING_KEYS = {"T64": 0, "T128": 1, "PAR64": 2, "WG_TARGET": 3, "WG_MINSTEPS": 4, "WG_MAXSTEPS": 5, "T3_ENABLE": 6,
                "T3_TARGET": 7, "T3_MINSTEPS": 8, "T3_NS": 9, "TAIL": 10, "WG_NS": 11, "ROI_TABLE": 12, "ROI_ROWS": 13, "STATIC_TAPS": 14,
-               "T128W": 15, "T3_MIX": 16, "SPLITK_TILE": 17}
+               "T128W": 15, "T3_MIX": 16, "SPLITK_TILE": 17, "T3_PER_ITEM": 18}
 
 _lib = None
 

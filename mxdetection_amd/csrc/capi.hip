@@ -16,8 +16,8 @@ void set_error(const char* fmt, ...) {
 void clear_error() { g_err[0] = 0; }
 
 // plan-time thresholds, index = MXDET_TUNE_* (include/mxdet_debug.h)
-static const long long kTuneDefault[MXDET_TUNE_COUNT] = {400, 1536, 1600, 3072, 64, 128, 1, 1536, 32, 2, 2, 2, 0, 2, 1, 1000000, 1, 0};
-static long long g_tune[MXDET_TUNE_COUNT] = {400, 1536, 1600, 3072, 64, 128, 1, 1536, 32, 2, 2, 2, 0, 2, 1, 1000000, 1, 0};
+static const long long kTuneDefault[MXDET_TUNE_COUNT] = {400, 1536, 1600, 3072, 64, 128, 1, 1536, 32, 2, 2, 2, 0, 2, 1, 1000000, 1, 0, 192};
+static long long g_tune[MXDET_TUNE_COUNT] = {400, 1536, 1600, 3072, 64, 128, 1, 1536, 32, 2, 2, 2, 0, 2, 1, 1000000, 1, 0, 192};
 long long tuning(int which) { return g_tune[which]; }
 
 }  // namespace mxdet

@@ -470,7 +470,14 @@ extern "C" int mxdet_conv2d_wgrad_grouped_plan(const mxdet_wgrad_item_t* items, 
   };
   int big_S = 0;
   {
-    const long long target = tuning(MXDET_TUNE_T3_TARGET);
+    // workgroups aimed for: the tuned total for a large group (the two groups of the single-GPU step hold 9-10 such layers),
+    // proportionally fewer for a small one (the per-stage groups of the exchange schedule hold 2-5: split as deep as the
+    // large groups, they paid more in slabs and folds than the extra workgroups gave back)
+    int n_t3 = 0;
+    for (int i = 0; i < n; ++i) n_t3 += is_big(items[i].desc) ? 1 : 0;
+    long long target = tuning(MXDET_TUNE_T3_TARGET);
+    const long long per_item = tuning(MXDET_TUNE_T3_PER_ITEM);
+    if (per_item > 0 && per_item * n_t3 < target) target = per_item * n_t3;
     const int smin = (int)tuning(MXDET_TUNE_T3_MINSTEPS);
     auto count = [&](int S) {
       long long c = 0;
